@@ -1,0 +1,190 @@
+/* insploray_hip.h — C ABI of the MI355X (gfx950) rendering backend for InsploRay's core-engine.
+ *
+ * This is the drop-in boundary: exactly the entry points a `insploray-hip-sys` FFI crate would bind so
+ * that `insploray::renderer::RayTracer` (reference core-engine/src/renderer.rs:13-173) keeps its public
+ * surface while the per-pixel integrator (integrator.rs:32-165), ray generation
+ * (cameras/pinhole_camera.rs:78-98), sky lookup (file_formats/exr.rs:13-24), accumulation
+ * (accumulators/) and resolve (full_buffer.rs:49-65, utils.rs:4-9) run as HIP kernels.
+ * All citations are relative to /root/reference/core-engine/src.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every host pointer argument is borrowed for the duration of the
+ *     call and copied before return;
+ *   - every function returns 0 on success, a negative IR_E* code on failure, never aborts;
+ *     ir_last_error(ctx) gives the message of the last failure on that context;
+ *   - a context is bound to ONE GPU (one process per GPU; multi-GPU = one context per rank, partial
+ *     radiance buffers combined by the caller with RCCL, see ir_set_partition / ir_bind_accumulator);
+ *   - a context is single-caller (not re-entrant), like RayTracer which is `&mut self` everywhere;
+ *   - there is no CPU fallback: without a HIP device ir_create fails.
+ */
+#ifndef INSPLORAY_HIP_H
+#define INSPLORAY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ir_context ir_context;
+
+enum {
+    IR_OK = 0,
+    IR_EINVAL = -1,   /* bad argument (null pointer, zero size, index out of range)            */
+    IR_EDEVICE = -2,  /* HIP runtime error (message in ir_last_error)                           */
+    IR_ESTATE = -3,   /* call order problem (e.g. render before a camera was set)               */
+    IR_ENOMEM = -4,   /* device or host allocation failed                                       */
+    IR_EIO = -5,      /* file could not be read / not a supported EXR                           */
+    IR_ELIMIT = -6    /* size beyond what this build supports                                   */
+};
+
+enum { IR_SKY_NEAREST = 0, IR_SKY_BILINEAR = 1 };  /* exr.rs:20-23 is NEAREST */
+enum { IR_PARTITION_NONE = 0, IR_PARTITION_TILES = 1, IR_PARTITION_SAMPLES = 2 };
+enum { IR_ACCEL_AUTO = 0, IR_ACCEL_LINEAR = 1, IR_ACCEL_LBVH = 2 };
+
+/* ABI version of this header (bumped on incompatible change). */
+uint32_t ir_abi_version(void);
+
+/* -------------------------------------------------------------------------------------------------
+ * Context.  Replaces RayTracer::new / Drop (renderer.rs:29-59, 182-191): where the reference spawns a
+ * 4-thread pool, this creates the device state (stream, events, buffers) on HIP device `device`.
+ * ------------------------------------------------------------------------------------------------- */
+int ir_create(ir_context** out_ctx, int device);
+void ir_destroy(ir_context* ctx);
+const char* ir_last_error(const ir_context* ctx);
+/* Message of the last failure of a call that had no usable context (ir_create). Thread-local. */
+const char* ir_last_global_error(void);
+
+/* Use an existing HIP stream (e.g. torch's current stream) for all launches and copies of this context.
+ * `hip_stream` is a hipStream_t passed as void*; NULL restores the context's own stream. */
+int ir_set_stream(ir_context* ctx, void* hip_stream);
+
+/* -------------------------------------------------------------------------------------------------
+ * Scene (scene.rs:5-41).  The reference Scene is a caller-owned AoS the renderer read-locks per render;
+ * the façade flattens it and calls these before ir_render (there is no dirty flag in the reference API).
+ *   spheres_xyzr : n x 4 floats  (Sphere.position.xyz, Sphere.radius)          scene.rs:27-31
+ *   material_id  : n x int32     (Sphere.material_id; <0 or >= n_materials => DEFAULT_MATERIAL,
+ *                                 integrator.rs:8-14,53-60)
+ *   materials9   : n x 9 floats  (albedo.xyz, roughness, metalic, emission_color.xyz, emissive_power)
+ *                                 scene.rs:5-12
+ * ------------------------------------------------------------------------------------------------- */
+int ir_set_spheres(ir_context* ctx, const float* spheres_xyzr, const int32_t* material_id, uint32_t n);
+int ir_set_materials(ir_context* ctx, const float* materials9, uint32_t n);
+/* Scene.default_sky_color (scene.rs:38), used when there is no skybox (integrator.rs:84-87). */
+int ir_set_sky_color(ir_context* ctx, const float rgb[3]);
+/* Scene.skybox = Some(ExrImage{pixels_buffer,width,height}) (exr.rs:6-10): rgb is w*h*3 floats, row-major,
+ * row 0 first (exr.rs:38).  rgb == NULL removes the skybox (Scene.skybox = None). */
+int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h);
+/* IR_SKY_NEAREST reproduces ExrImage::sample (exr.rs:13-24); IR_SKY_BILINEAR is an extension. */
+int ir_set_sky_filter(ir_context* ctx, int filter);
+/* Closest-hit structure: IR_ACCEL_LINEAR = the reference's linear scan (integrator.rs:106-127) over an
+ * LDS-staged SoA buffer; IR_ACCEL_LBVH = LBVH whose (t, index) equals the scan's; AUTO picks by count. */
+int ir_set_accel(ir_context* ctx, int accel);
+
+/* -------------------------------------------------------------------------------------------------
+ * Camera.  `dyn Camera` (cameras/mod.rs:7-17) is host code; PinholeCamera is the fast path.
+ * ------------------------------------------------------------------------------------------------- */
+/* PinholeCamera cached state (pinhole_camera.rs:7-23) as computed by ir_pinhole_compute:
+ * local_to_world column-major (glam Mat4), position, fov (radians), aspect_ratio. */
+int ir_set_pinhole(ir_context* ctx, const float local_to_world[16], const float position[3], float fov,
+                   float aspect_ratio);
+/* Any other Camera implementor: the façade evaluates get_ray(x,y) (cameras/mod.rs:8) on the host for every
+ * pixel and uploads them: rays = w*h*6 floats (origin.xyz, direction.xyz), pixel (x,y) at y*w+x. */
+int ir_set_primary_rays(ir_context* ctx, const float* rays, uint32_t w, uint32_t h);
+/* Host helper restating PinholeCamera::{compute_fov, compute_transformation_matrix,
+ * compute_camera_directions, set_image_resolutions} (pinhole_camera.rs:59-69,110-129).
+ * out_dirs9 = forward.xyz, up.xyz, right.xyz (may be NULL).  Needs no context and no GPU. */
+int ir_pinhole_compute(const float position[3], const float rotation_xyz[3], float focal_length,
+                       float sensor_size, uint32_t width, uint32_t height, float out_local_to_world[16],
+                       float* out_fov, float* out_aspect_ratio, float out_dirs9[9]);
+/* Host helper restating PinholeCamera::get_ray (pinhole_camera.rs:78-98) for one pixel: out6 = origin, dir. */
+int ir_pinhole_get_ray(const float local_to_world[16], const float position[3], float fov, float aspect_ratio,
+                       uint32_t width, uint32_t height, uint32_t x, uint32_t y, float out6[6]);
+
+/* -------------------------------------------------------------------------------------------------
+ * Integrator parameters (integrator.rs:17-20; reference defaults bounces=5, max_compulsory_bounces=2,
+ * renderer.rs:38-41).  `seed` keys the counter-based RNG that replaces rand::ThreadRng (sampler.rs:4-6):
+ * draw k of sample s of pixel p is a pure function of (seed, p, s, k).
+ * ------------------------------------------------------------------------------------------------- */
+int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory_bounces, uint64_t seed);
+
+/* Multi-GPU work split for this context (rank in [0, world)).
+ *   IR_PARTITION_TILES  : 64x64 tiles (renderer.rs:105-119) dealt round-robin; this rank renders tile t iff
+ *                         t % world == rank and leaves every other pixel's sum/count untouched.
+ *   IR_PARTITION_SAMPLES: every rank renders all pixels; ir_render(spp) renders the sample indices
+ *                         [base + rank*spp, base + (rank+1)*spp) where base = world * (samples already
+ *                         accumulated per rank), i.e. spp is PER RANK.
+ * Partial buffers are summed by the caller (RCCL reduce of ir_device_radiance / ir_device_counts). */
+int ir_set_partition(ir_context* ctx, int mode, uint32_t rank, uint32_t world);
+
+/* -------------------------------------------------------------------------------------------------
+ * Render.  Replaces RayTracer::render(scene, width, height, acc) (renderer.rs:95-162):
+ *   - resolution change reallocates and zeroes the accumulator (renderer.rs:80-93);
+ *   - accumulate == 0 zeroes it first (renderer.rs:99-103) == render_updated; accumulate != 0 == prepare_pixels;
+ *   - spp samples per pixel are added (the reference adds exactly 1 per call; spp = 1 reproduces it),
+ *     per pixel in sample order, so sums are bit-identical to spp successive 1-sample calls;
+ *   - blocks until the kernels have finished (the reference render() is synchronous).
+ * ------------------------------------------------------------------------------------------------- */
+int ir_render(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate);
+/* Same, but returns after enqueueing on the context's stream (for callers that own the stream). */
+int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate);
+int ir_synchronize(ir_context* ctx);
+
+/* RayTracer::get_output (renderer.rs:164-169): resolve (mean, Reinhard, gamma 1/2.2, clamp, 0xAARRGGBB) on the
+ * device and copy n = width*height u32 pixels to `out`.  Row 0 is the bottom row, as in the reference. */
+int ir_get_output_argb(ir_context* ctx, uint32_t* out, size_t n);
+/* Raw accumulator (Accumulator.framebuffer / sample_counts, full_buffer.rs:7-12): n x 4 floats, n x u32. */
+int ir_get_radiance(ir_context* ctx, float* sum_rgba, uint32_t* counts, size_t n);
+/* Overwrite the accumulator (checkpoint restore / tests).  Either pointer may be NULL (left unchanged). */
+int ir_set_radiance(ir_context* ctx, const float* sum_rgba, const uint32_t* counts, size_t n);
+/* Closest-hit sphere index of each pixel's primary ray (-1 = miss) for the current camera, scene and the
+ * size of the last render (or of ir_set_primary_rays); runs the same ray-generation and intersection code
+ * as the integrator.  out_t may be NULL. */
+int ir_get_primary_hits(ir_context* ctx, int32_t* out_index, float* out_t, size_t n);
+
+/* RayTracer::get_current_size (renderer.rs:65-67) and get_last_render_time (:171-173). */
+int ir_get_size(const ir_context* ctx, uint32_t* width, uint32_t* height);
+double ir_last_render_seconds(const ir_context* ctx);
+/* Device time of the integrator kernel launches of the last render (HIP events on the launch stream), ms,
+ * and how many launches that was. */
+double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches);
+/* Samples per pixel accumulated by this context since the last reset. */
+uint32_t ir_samples_accumulated(const ir_context* ctx);
+
+/* Device pointers of the accumulator (float4 sum per pixel, u32 count per pixel) for RCCL collectives issued
+ * by the caller (torch.distributed).  Valid until the next resolution change / ir_bind_accumulator. */
+void* ir_device_radiance(ir_context* ctx);
+void* ir_device_counts(ir_context* ctx);
+/* Render into caller-owned device memory instead (e.g. torch tensors): sum = n x float4, counts = n x u32
+ * for n = width*height of the next renders.  NULL, NULL returns to context-owned buffers. */
+int ir_bind_accumulator(ir_context* ctx, void* d_sum_rgba, void* d_counts, uint32_t width, uint32_t height);
+
+/* Work statistics of the NEXT render only (costs a little): algorithmic counts per §8(d) of SURVEY.md.
+ * After the render, ir_get_stats fills 5 x u64: samples, trace_ray calls, sphere tests, tests with
+ * discriminant >= 0, hits.  Counts are "as the reference would execute", i.e. per sample including the
+ * primary ray even where the kernel shares it between samples of a pixel. */
+int ir_enable_stats(ir_context* ctx, int enable);
+int ir_get_stats(ir_context* ctx, uint64_t out5[5]);
+
+/* -------------------------------------------------------------------------------------------------
+ * EXR (file_formats/exr.rs:26-49: ExrImage::load_exr_image == exr::read_first_rgba_layer_from_file).
+ * From-scratch reader: single/multi-part, scanline and tiled (level 0) files, HALF/FLOAT/UINT channels,
+ * NONE/RLE/ZIPS/ZIP compression (PIZ, PXR24, B44, DWA are reported as unsupported: IR_EIO); the first layer
+ * that has R, G and B; alpha dropped; pixel (x,y) of the data window at y*width+x, row 0 = top of the file.
+ * ir_exr_load allocates *out_rgb (w*h*3 floats) with malloc; release with ir_free.  Needs no GPU.
+ * ir_exr_last_error() gives the message of the last failed EXR call on this thread.
+ * ------------------------------------------------------------------------------------------------- */
+int ir_exr_load(const char* path, float** out_rgb, uint32_t* out_w, uint32_t* out_h);
+const char* ir_exr_last_error(void);
+/* Writer (fixtures, "save image" — a reference TODO, README.md:104): RGB scanline EXR; compression 0 = NONE,
+ * 1 = RLE, 2 = ZIPS, 3 = ZIP; pixel_type 1 = HALF, 2 = FLOAT. */
+int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int compression, int pixel_type);
+void ir_free(void* p);
+/* Host restatement of ExrImage::sample (exr.rs:13-24) so the façade keeps that public method. */
+int ir_exr_sample(const float* rgb, uint32_t w, uint32_t h, const float dir[3], float out_rgb[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSPLORAY_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI in include/insploray_hip.h (libinsploray_hip.so).
+
+This is the Python twin of the `insploray-hip-sys` FFI crate described in INTEGRATION.md: every prototype below
+is one declaration of include/insploray_hip.h.  There is no fallback: if the library has not been built
+(`make -C path_tracer_amd/csrc` or `__graft_entry__.build()`), importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libinsploray_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP backend first (make -C path_tracer_amd/csrc). "
+        "path_tracer_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+IR_OK = 0
+IR_EINVAL, IR_EDEVICE, IR_ESTATE, IR_ENOMEM, IR_EIO, IR_ELIMIT = -1, -2, -3, -4, -5, -6
+IR_SKY_NEAREST, IR_SKY_BILINEAR = 0, 1
+IR_PARTITION_NONE, IR_PARTITION_TILES, IR_PARTITION_SAMPLES = 0, 1, 2
+IR_ACCEL_AUTO, IR_ACCEL_LINEAR, IR_ACCEL_LBVH = 0, 1, 2
+
+c_float_p = C.POINTER(C.c_float)
+c_i32_p = C.POINTER(C.c_int32)
+c_u32_p = C.POINTER(C.c_uint32)
+c_u64_p = C.POINTER(C.c_uint64)
+ctx_p = C.c_void_p
+
+# name -> (restype, argtypes); the single source the symbol-export test iterates over
+PROTOTYPES = {
+    "ir_abi_version": (C.c_uint32, []),
+    "ir_create": (C.c_int, [C.POINTER(ctx_p), C.c_int]),
+    "ir_destroy": (None, [ctx_p]),
+    "ir_last_error": (C.c_char_p, [ctx_p]),
+    "ir_last_global_error": (C.c_char_p, []),
+    "ir_set_stream": (C.c_int, [ctx_p, C.c_void_p]),
+    "ir_set_spheres": (C.c_int, [ctx_p, c_float_p, c_i32_p, C.c_uint32]),
+    "ir_set_materials": (C.c_int, [ctx_p, c_float_p, C.c_uint32]),
+    "ir_set_sky_color": (C.c_int, [ctx_p, c_float_p]),
+    "ir_set_skybox": (C.c_int, [ctx_p, c_float_p, C.c_uint32, C.c_uint32]),
+    "ir_set_sky_filter": (C.c_int, [ctx_p, C.c_int]),
+    "ir_set_accel": (C.c_int, [ctx_p, C.c_int]),
+    "ir_set_pinhole": (C.c_int, [ctx_p, c_float_p, c_float_p, C.c_float, C.c_float]),
+    "ir_set_primary_rays": (C.c_int, [ctx_p, c_float_p, C.c_uint32, C.c_uint32]),
+    "ir_pinhole_compute": (C.c_int, [c_float_p, c_float_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                     c_float_p, c_float_p, c_float_p, c_float_p]),
+    "ir_pinhole_get_ray": (C.c_int, [c_float_p, c_float_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                     C.c_uint32, C.c_uint32, c_float_p]),
+    "ir_set_integrator": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "ir_set_partition": (C.c_int, [ctx_p, C.c_int, C.c_uint32, C.c_uint32]),
+    "ir_render": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    "ir_render_async": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    "ir_synchronize": (C.c_int, [ctx_p]),
+    "ir_get_output_argb": (C.c_int, [ctx_p, c_u32_p, C.c_size_t]),
+    "ir_get_radiance": (C.c_int, [ctx_p, c_float_p, c_u32_p, C.c_size_t]),
+    "ir_set_radiance": (C.c_int, [ctx_p, c_float_p, c_u32_p, C.c_size_t]),
+    "ir_get_primary_hits": (C.c_int, [ctx_p, c_i32_p, c_float_p, C.c_size_t]),
+    "ir_get_size": (C.c_int, [ctx_p, c_u32_p, c_u32_p]),
+    "ir_last_render_seconds": (C.c_double, [ctx_p]),
+    "ir_last_kernel_ms": (C.c_double, [ctx_p, c_u32_p]),
+    "ir_samples_accumulated": (C.c_uint32, [ctx_p]),
+    "ir_device_radiance": (C.c_void_p, [ctx_p]),
+    "ir_device_counts": (C.c_void_p, [ctx_p]),
+    "ir_bind_accumulator": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "ir_enable_stats": (C.c_int, [ctx_p, C.c_int]),
+    "ir_get_stats": (C.c_int, [ctx_p, c_u64_p]),
+    "ir_exr_load": (C.c_int, [C.c_char_p, C.POINTER(c_float_p), c_u32_p, c_u32_p]),
+    "ir_exr_last_error": (C.c_char_p, []),
+    "ir_exr_save": (C.c_int, [C.c_char_p, c_float_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    "ir_free": (None, [C.c_void_p]),
+    "ir_exr_sample": (C.c_int, [c_float_p, C.c_uint32, C.c_uint32, c_float_p, c_float_p]),
+}
+
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class InsplorayError(RuntimeError):
+    """Raised where the reference would panic (`unwrap`) or return Err."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+def fptr(a):
+    """float32 C-contiguous numpy array -> float*"""
+    return a.ctypes.data_as(c_float_p)
+
+
+def check(ctx, rc):
+    if rc != IR_OK:
+        msg = lib.ir_last_error(ctx) if ctx else lib.ir_last_global_error()
+        raise InsplorayError(rc, (msg or b"").decode("utf-8", "replace"))

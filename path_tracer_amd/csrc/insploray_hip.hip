@@ -1,0 +1,630 @@
+// insploray_hip.hip — host side of the C ABI declared in include/insploray_hip.h.
+//
+// Owns the device state that replaces the reference's CPU "device runtime" (the 4-thread pool and the two
+// crossbeam channels of core-engine/src/concurrency/**): one HIP stream, the scene buffers, the accumulator
+// (Accumulator.framebuffer / sample_counts, accumulators/full_buffer.rs:7-12) and the resolved ARGB frame.
+// There is no CPU fallback anywhere in this file: without a HIP device ir_create fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/insploray_hip.h"
+#include "pt_kernels.h"
+
+namespace {
+
+thread_local std::string g_global_error;
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct ir_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    mutable std::string err;
+
+    // scene (host copies kept so that the per-sphere shading table can be rebuilt when either side changes)
+    std::vector<float> h_spheres;   // n x 4
+    std::vector<int32_t> h_matid;   // n
+    std::vector<float> h_materials; // m x 9
+    bool shade_dirty = true;
+    uint32_t n_spheres = 0;
+    DeviceBuf d_spheres, d_shade;
+    float sky[3] = {0.0f, 0.0f, 0.0f};
+    DeviceBuf d_skybox;
+    uint32_t sky_w = 0, sky_h = 0;
+    int sky_filter = IR_SKY_NEAREST;
+    int accel = IR_ACCEL_AUTO;
+
+    // camera
+    bool have_pinhole = false;
+    float cam_m[16] = {0};
+    float cam_pos[3] = {0};
+    float cam_fov = 0.0f, cam_aspect = 1.0f;
+    DeviceBuf d_rays;
+    uint32_t rays_w = 0, rays_h = 0;
+
+    // integrator (reference defaults, renderer.rs:38-41)
+    uint32_t bounces = 5, rr_start = 2;
+    uint64_t seed = 0x0123456789ABCDEFull;
+
+    // partition
+    int part_mode = IR_PARTITION_NONE;
+    uint32_t rank = 0, world = 1;
+
+    // film
+    uint32_t width = 0, height = 0;
+    DeviceBuf d_sum, d_counts, d_argb, d_hit_idx, d_hit_t;
+    void* ext_sum = nullptr;
+    void* ext_counts = nullptr;
+    uint32_t ext_w = 0, ext_h = 0;
+    uint32_t samples_done = 0;
+
+    // stats
+    bool stats_enabled = false;
+    DeviceBuf d_stats;
+    bool stats_valid = false;
+
+    // timing
+    double last_seconds = 0.0;
+    bool events_recorded = false;
+    uint32_t last_launches = 0;
+};
+
+namespace {
+
+int fail(const ir_context* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) {
+        ctx->err = buf;
+    } else {
+        g_global_error = buf;
+    }
+    return code;
+}
+
+#define IR_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, IR_EDEVICE, "%s: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+#define IR_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != IR_OK) return rc_; \
+    } while (0)
+
+int ensure(ir_context* ctx, DeviceBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes && b.p) return IR_OK;
+    if (b.p) {
+        IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IR_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, IR_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    b.bytes = bytes;
+    return IR_OK;
+}
+
+void release(DeviceBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+int use_device(const ir_context* ctx) {
+    IR_HIP(ctx, hipSetDevice(ctx->device));
+    return IR_OK;
+}
+
+// blocking upload through the context's stream
+int upload(ir_context* ctx, DeviceBuf& b, const void* src, size_t bytes) {
+    IR_TRY(ensure(ctx, b, bytes));
+    if (bytes) {
+        IR_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return IR_OK;
+}
+
+float4* film_sum(ir_context* ctx) { return (float4*)(ctx->ext_sum ? ctx->ext_sum : ctx->d_sum.p); }
+uint32_t* film_counts(ir_context* ctx) { return (uint32_t*)(ctx->ext_counts ? ctx->ext_counts : ctx->d_counts.p); }
+
+// Scene -> device tables.  Material resolution follows integrator.rs:53-60 (material_id < 0 or out of range
+// => DEFAULT_MATERIAL, :8-14); brdf = albedo / PI (:68) and emission_color * emissive_power (:62) do not depend
+// on the path, so they are evaluated here once per sphere (same IEEE f32 operations as per hit).
+int rebuild_shade(ir_context* ctx) {
+    if (!ctx->shade_dirty) return IR_OK;
+    const uint32_t n = ctx->n_spheres;
+    const uint32_t m = (uint32_t)(ctx->h_materials.size() / 9);
+    std::vector<float> t((size_t)n * 8 + 8, 0.0f);
+    static const float def[9] = {1.0f, 1.0f, 1.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t i = 0; i < n; ++i) {
+        const int32_t id = ctx->h_matid[i];
+        const float* mt = (id < 0 || (uint32_t)id >= m) ? def : &ctx->h_materials[(size_t)id * 9];
+        float* o = &t[(size_t)i * 8];
+        o[0] = mt[0] / pt::kPi;
+        o[1] = mt[1] / pt::kPi;
+        o[2] = mt[2] / pt::kPi;
+        o[4] = mt[5] * mt[8];
+        o[5] = mt[6] * mt[8];
+        o[6] = mt[7] * mt[8];
+    }
+    IR_TRY(upload(ctx, ctx->d_shade, t.data(), t.size() * sizeof(float)));
+    ctx->shade_dirty = false;
+    return IR_OK;
+}
+
+void fill_camera(const ir_context* ctx, pt::CameraBlock& c) {
+    for (int i = 0; i < 3; ++i) {
+        c.xc[i] = ctx->cam_m[i];
+        c.yc[i] = ctx->cam_m[4 + i];
+        c.zc[i] = ctx->cam_m[8 + i];
+        c.pos[i] = ctx->cam_pos[i];
+    }
+    c.tan_half_fov = std::tan(ctx->cam_fov / 2.0f);  // pinhole_camera.rs:86, f32 tan once per render
+    c.aspect = ctx->cam_aspect;
+}
+
+int check_camera(ir_context* ctx, uint32_t w, uint32_t h, const float** rays) {
+    *rays = nullptr;
+    if (ctx->rays_w == w && ctx->rays_h == h && ctx->d_rays.p && w && h) {
+        *rays = (const float*)ctx->d_rays.p;
+        return IR_OK;
+    }
+    if (!ctx->have_pinhole) return fail(ctx, IR_ESTATE, "no camera: call ir_set_pinhole or ir_set_primary_rays (%ux%u) first", w, h);
+    return IR_OK;
+}
+
+int set_size(ir_context* ctx, uint32_t w, uint32_t h) {
+    if (ctx->ext_sum) {
+        if (ctx->ext_w != w || ctx->ext_h != h)
+            return fail(ctx, IR_EINVAL, "bound accumulator is %ux%u but render asked for %ux%u", ctx->ext_w, ctx->ext_h, w, h);
+        ctx->width = w;
+        ctx->height = h;
+        return IR_OK;
+    }
+    if (ctx->width == w && ctx->height == h && ctx->d_sum.p) return IR_OK;
+    // renderer.rs:84-88: a different resolution gets a fresh (zeroed) Accumulator
+    const size_t n = (size_t)w * h;
+    IR_TRY(ensure(ctx, ctx->d_sum, n * sizeof(float4)));
+    IR_TRY(ensure(ctx, ctx->d_counts, n * sizeof(uint32_t)));
+    IR_HIP(ctx, hipMemsetAsync(ctx->d_sum.p, 0, ctx->d_sum.bytes, ctx->stream));
+    IR_HIP(ctx, hipMemsetAsync(ctx->d_counts.p, 0, ctx->d_counts.bytes, ctx->stream));
+    ctx->width = w;
+    ctx->height = h;
+    ctx->samples_done = 0;
+    return IR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t ir_abi_version(void) { return 1; }
+
+const char* ir_last_global_error(void) { return g_global_error.c_str(); }
+
+int ir_create(ir_context** out_ctx, int device) {
+    if (!out_ctx) return fail(nullptr, IR_EINVAL, "ir_create: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, IR_EDEVICE, "ir_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, IR_EINVAL, "ir_create: device %d out of range [0,%d)", device, count);
+    ir_context* ctx = new (std::nothrow) ir_context();
+    if (!ctx) return fail(nullptr, IR_ENOMEM, "ir_create: out of host memory");
+    ctx->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        fail(nullptr, IR_EDEVICE, "ir_create: %s: %s", what, hipGetErrorString(err));
+        ir_destroy(ctx);
+        return IR_EDEVICE;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    ctx->stream = ctx->own_stream;
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = pt::init_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
+    *out_ctx = ctx;
+    return IR_OK;
+}
+
+void ir_destroy(ir_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_rays);
+    release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
+    release(ctx->d_stats);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* ir_last_error(const ir_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ir_set_stream(ir_context* ctx, void* hip_stream) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return IR_OK;
+}
+
+int ir_set_spheres(ir_context* ctx, const float* spheres_xyzr, const int32_t* material_id, uint32_t n) {
+    if (!ctx) return IR_EINVAL;
+    if (n && (!spheres_xyzr || !material_id)) return fail(ctx, IR_EINVAL, "ir_set_spheres: NULL array with n=%u", n);
+    if (n > pt::kMaxLdsSpheres)
+        return fail(ctx, IR_ELIMIT, "ir_set_spheres: %u spheres exceed the %u this build stages in LDS", n, pt::kMaxLdsSpheres);
+    IR_TRY(use_device(ctx));
+    ctx->h_spheres.assign(spheres_xyzr, spheres_xyzr + (size_t)n * 4);
+    ctx->h_matid.assign(material_id, material_id + n);
+    ctx->n_spheres = n;
+    ctx->shade_dirty = true;
+    IR_TRY(upload(ctx, ctx->d_spheres, ctx->h_spheres.data(), (size_t)n * 4 * sizeof(float)));
+    return IR_OK;
+}
+
+int ir_set_materials(ir_context* ctx, const float* materials9, uint32_t n) {
+    if (!ctx) return IR_EINVAL;
+    if (n && !materials9) return fail(ctx, IR_EINVAL, "ir_set_materials: NULL array with n=%u", n);
+    ctx->h_materials.assign(materials9, materials9 + (size_t)n * 9);
+    ctx->shade_dirty = true;
+    return IR_OK;
+}
+
+int ir_set_sky_color(ir_context* ctx, const float rgb[3]) {
+    if (!ctx) return IR_EINVAL;
+    if (!rgb) return fail(ctx, IR_EINVAL, "ir_set_sky_color: NULL");
+    memcpy(ctx->sky, rgb, sizeof(ctx->sky));
+    return IR_OK;
+}
+
+int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    if (!rgb) {
+        IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        release(ctx->d_skybox);
+        ctx->sky_w = ctx->sky_h = 0;
+        return IR_OK;
+    }
+    if (w == 0 || h == 0) return fail(ctx, IR_EINVAL, "ir_set_skybox: empty image %ux%u", w, h);
+    const size_t n = (size_t)w * h;
+    std::vector<float> padded(n * 4);
+    for (size_t i = 0; i < n; ++i) {
+        padded[4 * i + 0] = rgb[3 * i + 0];
+        padded[4 * i + 1] = rgb[3 * i + 1];
+        padded[4 * i + 2] = rgb[3 * i + 2];
+        padded[4 * i + 3] = 0.0f;
+    }
+    IR_TRY(upload(ctx, ctx->d_skybox, padded.data(), padded.size() * sizeof(float)));
+    ctx->sky_w = w;
+    ctx->sky_h = h;
+    return IR_OK;
+}
+
+int ir_set_sky_filter(ir_context* ctx, int filter) {
+    if (!ctx) return IR_EINVAL;
+    if (filter != IR_SKY_NEAREST) return fail(ctx, IR_EINVAL, "ir_set_sky_filter: filter %d is not supported by this build", filter);
+    ctx->sky_filter = filter;
+    return IR_OK;
+}
+
+int ir_set_accel(ir_context* ctx, int accel) {
+    if (!ctx) return IR_EINVAL;
+    if (accel != IR_ACCEL_AUTO && accel != IR_ACCEL_LINEAR)
+        return fail(ctx, IR_EINVAL, "ir_set_accel: mode %d is not supported by this build", accel);
+    ctx->accel = accel;
+    return IR_OK;
+}
+
+int ir_set_pinhole(ir_context* ctx, const float local_to_world[16], const float position[3], float fov, float aspect_ratio) {
+    if (!ctx) return IR_EINVAL;
+    if (!local_to_world || !position) return fail(ctx, IR_EINVAL, "ir_set_pinhole: NULL");
+    memcpy(ctx->cam_m, local_to_world, sizeof(ctx->cam_m));
+    memcpy(ctx->cam_pos, position, sizeof(ctx->cam_pos));
+    ctx->cam_fov = fov;
+    ctx->cam_aspect = aspect_ratio;
+    ctx->have_pinhole = true;
+    // a pinhole camera supersedes previously uploaded generic rays
+    ctx->rays_w = ctx->rays_h = 0;
+    return IR_OK;
+}
+
+int ir_set_primary_rays(ir_context* ctx, const float* rays, uint32_t w, uint32_t h) {
+    if (!ctx) return IR_EINVAL;
+    if (!rays || w == 0 || h == 0) return fail(ctx, IR_EINVAL, "ir_set_primary_rays: NULL or empty (%ux%u)", w, h);
+    IR_TRY(use_device(ctx));
+    IR_TRY(upload(ctx, ctx->d_rays, rays, (size_t)w * h * 6 * sizeof(float)));
+    ctx->rays_w = w;
+    ctx->rays_h = h;
+    return IR_OK;
+}
+
+int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory_bounces, uint64_t seed) {
+    if (!ctx) return IR_EINVAL;
+    if (bounces > 0x15555555u) return fail(ctx, IR_ELIMIT, "ir_set_integrator: bounces %u too large", bounces);
+    ctx->bounces = bounces;
+    ctx->rr_start = max_compulsory_bounces;
+    ctx->seed = seed;
+    return IR_OK;
+}
+
+int ir_set_partition(ir_context* ctx, int mode, uint32_t rank, uint32_t world) {
+    if (!ctx) return IR_EINVAL;
+    if (mode != IR_PARTITION_NONE && mode != IR_PARTITION_TILES && mode != IR_PARTITION_SAMPLES)
+        return fail(ctx, IR_EINVAL, "ir_set_partition: unknown mode %d", mode);
+    if (world == 0 || rank >= world) return fail(ctx, IR_EINVAL, "ir_set_partition: rank %u not in [0,%u)", rank, world);
+    ctx->part_mode = mode;
+    ctx->rank = rank;
+    ctx->world = world;
+    return IR_OK;
+}
+
+int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate) {
+    if (!ctx) return IR_EINVAL;
+    if ((uint64_t)width * height > 0x7fffffffull / 8)
+        return fail(ctx, IR_ELIMIT, "ir_render: %ux%u exceeds the supported frame size", width, height);
+    IR_TRY(use_device(ctx));
+    ctx->events_recorded = false;
+    ctx->last_launches = 0;
+    ctx->stats_valid = false;
+    IR_TRY(set_size(ctx, width, height));
+    if (width == 0 || height == 0) return IR_OK;  // RayTracer::new(0,0) then render(…,0,0,…) is a no-op loop
+    const size_t n = (size_t)width * height;
+    if (!accumulate) {
+        // renderer.rs:99-103
+        IR_HIP(ctx, hipMemsetAsync(film_sum(ctx), 0, n * sizeof(float4), ctx->stream));
+        IR_HIP(ctx, hipMemsetAsync(film_counts(ctx), 0, n * sizeof(uint32_t), ctx->stream));
+        ctx->samples_done = 0;
+    }
+    if (spp == 0) return IR_OK;
+    const float* rays = nullptr;
+    IR_TRY(check_camera(ctx, width, height, &rays));
+    IR_TRY(rebuild_shade(ctx));
+    IR_TRY(ensure(ctx, ctx->d_spheres, 16));
+
+    pt::RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_camera(ctx, a.cam);
+    a.rays = rays;
+    a.w = width;
+    a.h = height;
+    a.spheres = (const float4*)ctx->d_spheres.p;
+    a.shade = (const float4*)ctx->d_shade.p;
+    a.n_spheres = ctx->n_spheres;
+    memcpy(a.sky, ctx->sky, sizeof(a.sky));
+    a.skybox = (const float4*)ctx->d_skybox.p;
+    a.sky_w = ctx->sky_w;
+    a.sky_h = ctx->sky_h;
+    a.sky_filter = ctx->sky_filter;
+    a.bounces = ctx->bounces;
+    a.rr_start = ctx->rr_start;
+    a.seed_lo = (uint32_t)(ctx->seed & 0xffffffffu);
+    a.seed_hi = (uint32_t)(ctx->seed >> 32);
+    a.sum = film_sum(ctx);
+    a.counts = film_counts(ctx);
+    a.tiles_x = (width + pt::kTile - 1) / pt::kTile;
+    a.n_tiles = a.tiles_x * ((height + pt::kTile - 1) / pt::kTile);
+    a.tile_rank = (ctx->part_mode == IR_PARTITION_TILES) ? ctx->rank : 0;
+    a.tile_world = (ctx->part_mode == IR_PARTITION_TILES) ? ctx->world : 1;
+
+    if (ctx->stats_enabled) {
+        IR_TRY(ensure(ctx, ctx->d_stats, 5 * sizeof(unsigned long long)));
+        IR_HIP(ctx, hipMemsetAsync(ctx->d_stats.p, 0, 5 * sizeof(unsigned long long), ctx->stream));
+        a.stats = (unsigned long long*)ctx->d_stats.p;
+    }
+
+    // sample indices of this call
+    uint64_t base = ctx->samples_done;
+    if (ctx->part_mode == IR_PARTITION_SAMPLES) base = (uint64_t)ctx->samples_done * ctx->world + (uint64_t)ctx->rank * spp;
+    if (base + spp > 0xffffffffull) return fail(ctx, IR_ELIMIT, "ir_render: sample index overflow");
+
+    // bound the work of one launch (pixels x spheres x samples) so that a launch stays well under a second
+    const double unit = (double)n * (double)(ctx->n_spheres < 8 ? 8 : ctx->n_spheres);
+    uint32_t chunk = (uint32_t)std::fmin(4096.0, std::fmax(1.0, 4.0e12 / unit));
+    IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    uint32_t done = 0;
+    while (done < spp) {
+        const uint32_t now = (spp - done < chunk) ? (spp - done) : chunk;
+        a.spp = now;
+        a.sample_base = (uint32_t)(base + done);
+        IR_HIP(ctx, pt::launch_render(a, ctx->stats_enabled, ctx->stream));
+        done += now;
+        ctx->last_launches++;
+    }
+    IR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->events_recorded = true;
+    ctx->samples_done += spp;
+    if (ctx->stats_enabled) {
+        ctx->stats_valid = true;
+        ctx->stats_enabled = false;  // one render only
+    }
+    return IR_OK;
+}
+
+int ir_synchronize(ir_context* ctx) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IR_OK;
+}
+
+int ir_render(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate) {
+    if (!ctx) return IR_EINVAL;
+    const auto t0 = std::chrono::steady_clock::now();
+    IR_TRY(ir_render_async(ctx, width, height, spp, accumulate));
+    IR_TRY(ir_synchronize(ctx));
+    ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return IR_OK;
+}
+
+int ir_get_output_argb(ir_context* ctx, uint32_t* out, size_t n) {
+    if (!ctx) return IR_EINVAL;
+    const size_t have = (size_t)ctx->width * ctx->height;
+    if (n != have) return fail(ctx, IR_EINVAL, "ir_get_output_argb: n=%zu but the frame has %zu pixels", n, have);
+    if (n == 0) return IR_OK;
+    if (!out) return fail(ctx, IR_EINVAL, "ir_get_output_argb: NULL");
+    IR_TRY(use_device(ctx));
+    IR_TRY(ensure(ctx, ctx->d_argb, n * sizeof(uint32_t)));
+    IR_HIP(ctx, pt::launch_resolve(film_sum(ctx), film_counts(ctx), (uint32_t*)ctx->d_argb.p, n, ctx->stream));
+    IR_HIP(ctx, hipMemcpyAsync(out, ctx->d_argb.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IR_OK;
+}
+
+int ir_get_radiance(ir_context* ctx, float* sum_rgba, uint32_t* counts, size_t n) {
+    if (!ctx) return IR_EINVAL;
+    const size_t have = (size_t)ctx->width * ctx->height;
+    if (n != have) return fail(ctx, IR_EINVAL, "ir_get_radiance: n=%zu but the frame has %zu pixels", n, have);
+    if (n == 0) return IR_OK;
+    IR_TRY(use_device(ctx));
+    if (sum_rgba) IR_HIP(ctx, hipMemcpyAsync(sum_rgba, film_sum(ctx), n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (counts) IR_HIP(ctx, hipMemcpyAsync(counts, film_counts(ctx), n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IR_OK;
+}
+
+int ir_set_radiance(ir_context* ctx, const float* sum_rgba, const uint32_t* counts, size_t n) {
+    if (!ctx) return IR_EINVAL;
+    const size_t have = (size_t)ctx->width * ctx->height;
+    if (n != have) return fail(ctx, IR_EINVAL, "ir_set_radiance: n=%zu but the frame has %zu pixels", n, have);
+    if (n == 0) return IR_OK;
+    IR_TRY(use_device(ctx));
+    if (sum_rgba) IR_HIP(ctx, hipMemcpyAsync(film_sum(ctx), sum_rgba, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    if (counts) IR_HIP(ctx, hipMemcpyAsync(film_counts(ctx), counts, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IR_OK;
+}
+
+int ir_get_primary_hits(ir_context* ctx, int32_t* out_index, float* out_t, size_t n) {
+    if (!ctx) return IR_EINVAL;
+    uint32_t w = ctx->width, h = ctx->height;
+    if ((w == 0 || h == 0) && ctx->rays_w) {
+        w = ctx->rays_w;
+        h = ctx->rays_h;
+    }
+    const size_t have = (size_t)w * h;
+    if (n != have) return fail(ctx, IR_EINVAL, "ir_get_primary_hits: n=%zu but the frame has %zu pixels", n, have);
+    if (n == 0) return IR_OK;
+    if (!out_index) return fail(ctx, IR_EINVAL, "ir_get_primary_hits: NULL");
+    IR_TRY(use_device(ctx));
+    const float* rays = nullptr;
+    IR_TRY(check_camera(ctx, w, h, &rays));
+    IR_TRY(ensure(ctx, ctx->d_spheres, 16));
+    IR_TRY(ensure(ctx, ctx->d_hit_idx, n * sizeof(int32_t)));
+    if (out_t) IR_TRY(ensure(ctx, ctx->d_hit_t, n * sizeof(float)));
+    pt::HitsArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_camera(ctx, a.cam);
+    a.rays = rays;
+    a.w = w;
+    a.h = h;
+    a.spheres = (const float4*)ctx->d_spheres.p;
+    a.n_spheres = ctx->n_spheres;
+    a.out_idx = (int32_t*)ctx->d_hit_idx.p;
+    a.out_t = out_t ? (float*)ctx->d_hit_t.p : nullptr;
+    IR_HIP(ctx, pt::launch_primary_hits(a, ctx->stream));
+    IR_HIP(ctx, hipMemcpyAsync(out_index, ctx->d_hit_idx.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_t) IR_HIP(ctx, hipMemcpyAsync(out_t, ctx->d_hit_t.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IR_OK;
+}
+
+int ir_get_size(const ir_context* ctx, uint32_t* width, uint32_t* height) {
+    if (!ctx) return IR_EINVAL;
+    if (width) *width = ctx->width;
+    if (height) *height = ctx->height;
+    return IR_OK;
+}
+
+double ir_last_render_seconds(const ir_context* ctx) { return ctx ? ctx->last_seconds : 0.0; }
+
+double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches) {
+    if (n_launches) *n_launches = ctx ? ctx->last_launches : 0;
+    if (!ctx || !ctx->events_recorded) return 0.0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0.0;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return 0.0;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return 0.0;
+    return (double)ms;
+}
+
+uint32_t ir_samples_accumulated(const ir_context* ctx) { return ctx ? ctx->samples_done : 0; }
+
+void* ir_device_radiance(ir_context* ctx) { return ctx ? (void*)film_sum(ctx) : nullptr; }
+void* ir_device_counts(ir_context* ctx) { return ctx ? (void*)film_counts(ctx) : nullptr; }
+
+int ir_bind_accumulator(ir_context* ctx, void* d_sum_rgba, void* d_counts, uint32_t width, uint32_t height) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!d_sum_rgba && !d_counts) {
+        ctx->ext_sum = ctx->ext_counts = nullptr;
+        ctx->ext_w = ctx->ext_h = 0;
+        ctx->width = ctx->height = 0;  // next render reallocates the context-owned film
+        ctx->samples_done = 0;
+        return IR_OK;
+    }
+    if (!d_sum_rgba || !d_counts) return fail(ctx, IR_EINVAL, "ir_bind_accumulator: both buffers are required");
+    if (((uintptr_t)d_sum_rgba & 15u) || ((uintptr_t)d_counts & 3u)) return fail(ctx, IR_EINVAL, "ir_bind_accumulator: misaligned buffer");
+    ctx->ext_sum = d_sum_rgba;
+    ctx->ext_counts = d_counts;
+    ctx->ext_w = width;
+    ctx->ext_h = height;
+    ctx->width = width;
+    ctx->height = height;
+    ctx->samples_done = 0;
+    return IR_OK;
+}
+
+int ir_enable_stats(ir_context* ctx, int enable) {
+    if (!ctx) return IR_EINVAL;
+    ctx->stats_enabled = enable != 0;
+    return IR_OK;
+}
+
+int ir_get_stats(ir_context* ctx, uint64_t out5[5]) {
+    if (!ctx) return IR_EINVAL;
+    if (!out5) return fail(ctx, IR_EINVAL, "ir_get_stats: NULL");
+    if (!ctx->stats_valid) return fail(ctx, IR_ESTATE, "ir_get_stats: the last render did not collect statistics");
+    IR_TRY(use_device(ctx));
+    unsigned long long tmp[5];
+    IR_HIP(ctx, hipMemcpyAsync(tmp, ctx->d_stats.p, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 5; ++i) out5[i] = tmp[i];
+    return IR_OK;
+}
+
+void ir_free(void* p) { free(p); }
+
+}  // extern "C"

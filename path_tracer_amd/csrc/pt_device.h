@@ -1,0 +1,246 @@
+// pt_device.h — device-side building blocks of the gfx950 integrator (wave64, FP32 VALU).
+//
+// Arithmetic contract: this translation unit is compiled with -ffp-contract=off and without fast-math,
+// hipcc's default correctly rounded f32 divide/sqrt stays on.  Every expression below is written in the
+// operation order of the reference (glam 0.30 scalar Vec3 semantics), so that results are bit-identical
+// to an IEEE-754 CPU evaluation in the same order.  Citations: /root/reference/core-engine/src.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_DEV __device__ __forceinline__
+
+namespace pt {
+
+constexpr float kPi = 3.14159265358979323846264338327950288f;  // std::f32::consts::PI
+constexpr float kTwoPi = 2.0f * kPi;                            // Rust folds 2.0 * PI to one f32 constant
+constexpr float kEps = 1.1920929e-07f;                          // f32::EPSILON
+constexpr float kF32Max = 3.40282347e+38f;                      // f32::MAX
+
+struct f3 {
+    float x, y, z;
+};
+PT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+PT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+PT_DEV f3 cross(f3 a, f3 b) {  // glam vec3.rs
+    return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+PT_DEV f3 normalize(f3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }  // glam: v * length_recip()
+
+// ----------------------------------------------------------------------------------------------------
+// Counter-based RNG (replaces rand::ThreadRng, sampler.rs:4-6,21-28).
+// draw k of sample s of pixel p under a 64-bit seed:
+//     pkey = mix32(p ^ seed_lo);  skey = mix32(pkey + s*0x9E3779B9 + seed_hi);  u = mix32(skey + k*0x85EBCA6B)
+//     f    = (u >> 8) * 2^-24          (rand 0.9 StandardUniform for f32: 24 high bits, [0,1))
+// mix32 is a bijective xorshift-multiply finaliser ("lowbias32" family), so within a pixel distinct s give
+// distinct stream keys and within a stream distinct k give distinct outputs.
+// ----------------------------------------------------------------------------------------------------
+PT_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x21f0aaadu;
+    x ^= x >> 15;
+    x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+PT_DEV uint32_t pixel_key(uint32_t seed_lo, uint32_t pixel) { return mix32(pixel ^ seed_lo); }
+PT_DEV uint32_t sample_key(uint32_t seed_hi, uint32_t pkey, uint32_t sample) {
+    return mix32(pkey + sample * 0x9e3779b9u + seed_hi);
+}
+PT_DEV float draw(uint32_t skey, uint32_t k) {
+    return (float)(mix32(skey + k * 0x85ebca6bu) >> 8) * 5.9604644775390625e-08f;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Polynomial transcendentals: plain + - * / (no FMA, no hardware sin/cos/rcp approximations), so the
+// same source order evaluated on a CPU gives the same bits.  Classic single-precision minimax sets.
+// ----------------------------------------------------------------------------------------------------
+PT_DEV void sincos_poly(float x, float& s_out, float& c_out) {  // 0 <= x <= 2*pi
+    const float FOPI = 1.27323954473516f;
+    const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+    int j = (int)(FOPI * x);
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    float r = ((x - y * DP1) - y * DP2) - y * DP3;
+    float z = r * r;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z -
+               0.5f * z + 1.0f;
+    int q = (j >> 1) & 3;
+    float s = (q & 1) ? cp : sp;
+    float c = (q & 1) ? sp : cp;
+    s = (q & 2) ? -s : s;
+    c = ((q == 1) || (q == 2)) ? -c : c;
+    s_out = s;
+    c_out = c;
+}
+PT_DEV float asin_core(float a) {  // |a| <= 0.5
+    float z = a * a;
+    return ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z +
+            1.6666752422e-1f) * z * a + a;
+}
+PT_DEV float acos_poly(float x) {
+    const float PIO2 = 1.5707963267948966f;
+    if (x > 0.5f) return 2.0f * asin_core(__builtin_sqrtf(0.5f * (1.0f - x)));
+    if (x < -0.5f) return kPi - 2.0f * asin_core(__builtin_sqrtf(0.5f * (1.0f + x)));
+    return PIO2 - asin_core(x);
+}
+PT_DEV float atan_pos(float x) {  // x >= 0
+    const float PIO2 = 1.5707963267948966f, PIO4 = 0.7853981633974483f;
+    float y;
+    if (x > 2.414213562373095f) {
+        y = PIO2;
+        x = -(1.0f / x);
+    } else if (x > 0.4142135623730950f) {
+        y = PIO4;
+        x = (x - 1.0f) / (x + 1.0f);
+    } else {
+        y = 0.0f;
+    }
+    float z = x * x;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+    return y;
+}
+PT_DEV float atan2_poly(float y, float x) {
+    float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    float a;
+    if (ax == 0.0f && ay == 0.0f) {
+        a = 0.0f;
+    } else if (ax == 0.0f) {
+        a = 1.5707963267948966f;
+    } else {
+        a = atan_pos(ay / ax);
+    }
+    if (x < 0.0f) a = kPi - a;
+    if (y < 0.0f) a = -a;
+    return a;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Camera block (pinhole_camera.rs:7-23 cached state; tan(fov/2) evaluated once on the host, :86)
+// ----------------------------------------------------------------------------------------------------
+struct CameraBlock {
+    float xc[3], yc[3], zc[3];  // x/y/z axis columns of local_to_world (upper 3 rows)
+    float pos[3];
+    float tan_half_fov;
+    float aspect;
+};
+
+struct Ray {
+    f3 o, d;
+};
+
+// PinholeCamera::get_ray, pinhole_camera.rs:78-98
+PT_DEV Ray pinhole_ray(const CameraBlock& cam, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
+    float vx = ((float)x + 0.5f) / (float)w;
+    float vy = ((float)y + 0.5f) / (float)h;
+    vx = (vx * 2.0f - 1.0f) * cam.tan_half_fov;
+    vy = (vy * 2.0f - 1.0f) * cam.tan_half_fov;
+    vx *= cam.aspect;
+    f3 X = mk3(cam.xc[0], cam.xc[1], cam.xc[2]);
+    f3 Y = mk3(cam.yc[0], cam.yc[1], cam.yc[2]);
+    f3 Z = mk3(cam.zc[0], cam.zc[1], cam.zc[2]);
+    f3 res = X * vx;         // glam Mat4::transform_vector3
+    res = Y * vy + res;
+    res = Z * -1.0f + res;
+    Ray r;
+    r.o = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    r.d = normalize(res);
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Closest hit: linear scan over an LDS-staged SoA buffer.  s_sph[i] = (cx, cy, cz, r*r).
+// integrator.rs:95-134: per sphere  oc = o - c; a = d.d; b = 2(d.oc); c = oc.oc - r*r;
+// disc = b*b - (4a)*c; skip if disc < 0; t = (-b - sqrt(disc)) / (2a); accept iff t > 0 && t < best.
+// a, 4a and 2a do not depend on the sphere and are hoisted (same values).
+// ----------------------------------------------------------------------------------------------------
+struct HitRec {
+    float t;
+    int idx;  // -1 = miss
+};
+
+template <bool STATS>
+PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f3 d, uint32_t& disc_pos) {
+    float best = kF32Max;
+    int idx = -1;
+    const float a = dot(d, d);
+    const float a4 = 4.0f * a;
+    const float a2 = 2.0f * a;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float4 s = s_sph[i];
+        f3 oc = o - mk3(s.x, s.y, s.z);
+        float b = 2.0f * dot(d, oc);
+        float c = dot(oc, oc) - s.w;
+        float disc = b * b - a4 * c;
+        if (disc < 0.0f) continue;
+        if (STATS) disc_pos++;
+        float sq = __builtin_sqrtf(disc);
+        float t = (-b - sq) / a2;
+        if (t > 0.0f && t < best) {
+            idx = (int)i;
+            best = t;
+        }
+    }
+    HitRec h;
+    h.t = best;
+    h.idx = idx;
+    return h;
+}
+
+// integrator.rs:136-156 closest_hit: hp = (o - c) + t*d; n = normalize(hp); pos = hp + c
+PT_DEV void hit_geometry(float4 sph, f3 o, f3 d, float t, f3& pos, f3& nrm) {
+    f3 c = mk3(sph.x, sph.y, sph.z);
+    f3 oc = o - c;
+    f3 hp = oc + t * d;
+    nrm = normalize(hp);
+    pos = hp + c;
+}
+
+// sampler.rs:8-18,43-53
+PT_DEV f3 sample_hemisphere(f3 n, float r1, float r2) {
+    float phi = kTwoPi * r1;
+    float r = __builtin_sqrtf(r2);
+    float sn, cs;
+    sincos_poly(phi, sn, cs);
+    f3 local = mk3(r * cs, r * sn, 1.0f - r);
+    f3 up = (__builtin_fabsf(n.z) < 0.999f) ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
+    f3 tangent = normalize(cross(up, n));
+    f3 bitangent = cross(n, tangent);
+    return local.x * tangent + local.y * bitangent + local.z * n;
+}
+
+// ExrImage::sample, exr.rs:13-24 (nearest texel).  Texels are stored padded to float4.
+PT_DEV uint32_t texel_index(float f, uint32_t n) {
+    // Rust: f.floor() as usize % n  (saturating cast: NaN / negative -> 0)
+    f = __builtin_floorf(f);
+    uint32_t i = (f > 0.0f) ? (uint32_t)__builtin_fminf(f, 4294967040.0f) : 0u;
+    if (i >= n) i = i % n;
+    return i;
+}
+PT_DEV void sky_uv(f3 dir, float& u, float& v) {
+    f3 d = normalize(dir);
+    float cy = d.y;
+    cy = (cy < -1.0f) ? -1.0f : cy;
+    cy = (cy > 1.0f) ? 1.0f : cy;
+    float theta = acos_poly(cy);
+    float phi = atan2_poly(d.z, d.x);
+    u = (phi + kPi) / kTwoPi;
+    v = theta / kPi;
+}
+PT_DEV f3 sky_nearest(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, f3 dir) {
+    float u, v;
+    sky_uv(dir, u, v);
+    uint32_t x = texel_index(u * (float)sw, sw);
+    uint32_t y = texel_index(v * (float)sh, sh);
+    float4 t = sky[(size_t)y * sw + x];
+    return mk3(t.x, t.y, t.z);
+}
+
+}  // namespace pt

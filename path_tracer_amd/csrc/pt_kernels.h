@@ -1,0 +1,59 @@
+// pt_kernels.h — launch interface between the C-ABI host code (insploray_hip.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_device.h"
+
+namespace pt {
+
+constexpr uint32_t kTile = 64;        // reference tile edge, renderer.rs:105
+constexpr uint32_t kBlockEdge = 16;   // one 256-thread workgroup renders 16x16 pixels = 4 waves of 8x8
+constexpr uint32_t kBlocksPerTile = (kTile / kBlockEdge) * (kTile / kBlockEdge);
+constexpr uint32_t kMaxLdsSpheres = 10000;  // 10000 * 16 B = 160000 B <= 160 KiB LDS of one CU
+
+struct RenderArgs {
+    CameraBlock cam;
+    const float* rays;  // generic-camera primary rays (6 floats per pixel) or nullptr => pinhole
+    uint32_t w, h;
+
+    const float4* spheres;      // (cx, cy, cz, r)
+    const float4* shade;        // per sphere: [2i] = (brdf.rgb, 0) with brdf = albedo / PI, [2i+1] = (emission*power, 0)
+    uint32_t n_spheres;
+
+    float sky[3];
+    const float4* skybox;  // rgb padded to float4, row 0 first; nullptr => constant sky
+    uint32_t sky_w, sky_h;
+    int sky_filter;
+
+    uint32_t bounces, rr_start;
+    uint32_t seed_lo, seed_hi;
+    uint32_t spp, sample_base;
+
+    float4* sum;       // running radiance sum (rgb) + sample weight (a)
+    uint32_t* counts;  // samples per pixel
+
+    // tile partition: this launch renders tiles t = tile_rank + k * tile_world, k = 0 .. n_owned_tiles-1
+    uint32_t tiles_x, n_tiles, tile_rank, tile_world;
+
+    unsigned long long* stats;  // 5 counters or nullptr (only read by the STATS instantiation)
+};
+
+struct HitsArgs {
+    CameraBlock cam;
+    const float* rays;
+    uint32_t w, h;
+    const float4* spheres;
+    uint32_t n_spheres;
+    int32_t* out_idx;
+    float* out_t;  // may be nullptr
+};
+
+// All launchers enqueue on `stream` and return the HIP status of the launch.
+hipError_t launch_render(const RenderArgs& a, bool stats, hipStream_t stream);
+hipError_t launch_primary_hits(const HitsArgs& a, hipStream_t stream);
+hipError_t launch_resolve(const float4* sum, const uint32_t* counts, uint32_t* argb, size_t n, hipStream_t stream);
+// one-time per-device kernel attribute setup (dynamic LDS above 64 KiB)
+hipError_t init_kernels();
+
+}  // namespace pt

@@ -1,0 +1,264 @@
+// pt_kernels.hip — gfx950 (CDNA4, wave64) kernels of the InsploRay integrator.
+//
+// render_kernel: one lane owns one pixel and runs its samples in order (regeneration loop): when a path
+// ends, the lane adds it to its running sum and restarts from the pixel's primary hit with the next sample
+// index.  The primary ray has no jitter (pinhole_camera.rs:81-84), so ray generation and the first
+// closest-hit are shared by all samples of the pixel; everything after it is per sample.  Per-pixel sums
+// are therefore formed in exactly the order of the reference (one sample per render() call,
+// tile_buffer.rs:24-28 -> full_buffer.rs:107-125), which makes them bit-comparable to the CPU oracle.
+// The sphere SoA buffer is staged in LDS once per workgroup and read wave-uniformly (LDS broadcast).
+#include "pt_kernels.h"
+
+namespace pt {
+
+namespace {
+
+__device__ __forceinline__ f3 sky_eval(const RenderArgs& a, f3 dir) {
+    if (a.skybox) {
+        return sky_nearest(a.skybox, a.sky_w, a.sky_h, dir);
+    }
+    return mk3(a.sky[0], a.sky[1], a.sky[2]);
+}
+
+// (x, y) of this lane: 1D grid over the 16x16 blocks of the owned 64x64 tiles; waves are 8x8 pixels.
+__device__ __forceinline__ bool lane_pixel(uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world, uint32_t w,
+                                           uint32_t h, uint32_t& x, uint32_t& y) {
+    const uint32_t k = blockIdx.x / kBlocksPerTile;
+    const uint32_t sub = blockIdx.x % kBlocksPerTile;
+    const uint32_t tile = tile_rank + k * tile_world;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    x = tx * kTile + (sub & 3) * kBlockEdge + (wave & 1) * 8 + (lane & 7);
+    y = ty * kTile + (sub >> 2) * kBlockEdge + (wave >> 1) * 8 + (lane >> 3);
+    return x < w && y < h;
+}
+
+__device__ __forceinline__ void stage_spheres(float4* s_sph, const float4* __restrict__ g, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float4 s = g[i];
+        s.w = s.w * s.w;  // radius * radius (integrator.rs:111), same product evaluated once
+        s_sph[i] = s;
+    }
+    __syncthreads();
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
+    extern __shared__ float4 s_sph[];
+    stage_spheres(s_sph, a.spheres, a.n_spheres);
+
+    uint32_t x, y;
+    if (!lane_pixel(a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
+    const uint32_t pixel = y * a.w + x;
+
+    // per-lane work statistics (STATS only): traces, discriminant >= 0 tests, hits
+    uint32_t n_traces = 0, n_disc = 0, n_hits = 0;
+    uint32_t disc0 = 0;
+
+    // ---- primary ray + primary closest hit (shared by all samples of the pixel)
+    Ray r0;
+    if (a.rays) {
+        const float* p = a.rays + 6 * (size_t)pixel;
+        r0.o = mk3(p[0], p[1], p[2]);
+        r0.d = mk3(p[3], p[4], p[5]);
+    } else {
+        r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
+    }
+    float4 acc = a.sum[pixel];
+    const uint32_t B = a.bounces, R = a.rr_start, spp = a.spp;
+
+    if (B == 0) {
+        // integrator.rs:47: the bounce loop never runs, every sample is (0,0,0,1)
+        for (uint32_t s = 0; s < spp; ++s) {
+            acc.x += 0.0f; acc.y += 0.0f; acc.z += 0.0f; acc.w += 1.0f;
+        }
+    } else {
+        const HitRec h0 = trace_linear<STATS>(s_sph, a.n_spheres, r0.o, r0.d, disc0);
+        if (h0.idx < 0) {
+            // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89)
+            f3 light = mk3(0.0f, 0.0f, 0.0f) + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
+            for (uint32_t s = 0; s < spp; ++s) {
+                acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
+            }
+            if (STATS) {
+                n_traces = spp;
+                n_disc = disc0 * spp;
+            }
+        } else {
+            f3 pos0, nrm0;
+            {
+                const float4 sp = s_sph[h0.idx];
+                hit_geometry(sp, r0.o, r0.d, h0.t, pos0, nrm0);
+            }
+            const int idx0 = h0.idx;
+            const uint32_t pkey = pixel_key(a.seed_lo, pixel);
+
+            uint32_t s = 0, b = 0;
+            uint32_t skey = sample_key(a.seed_hi, pkey, a.sample_base);
+            f3 pos = pos0, nrm = nrm0;
+            int idx = idx0;
+            f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
+            if (STATS) { n_traces = 1; n_disc = disc0; n_hits = 1; }
+
+            while (s < spp) {
+                // ---- shade the hit of bounce b (integrator.rs:50-81)
+                const float4 m_brdf = a.shade[2 * idx];
+                const float4 m_emit = a.shade[2 * idx + 1];
+                light = light + mk3(m_emit.x, m_emit.y, m_emit.z) * contrib;
+                const float r1 = draw(skey, 3 * b);
+                const float r2 = draw(skey, 3 * b + 1);
+                const f3 wi = sample_hemisphere(nrm, r1, r2);
+                const float cos_theta = __builtin_fmaxf(dot(wi, nrm), 0.0f);
+                const float pdf = cos_theta / kPi;
+                contrib = contrib * (mk3(m_brdf.x, m_brdf.y, m_brdf.z) * cos_theta / pdf);
+                bool done = false;
+                if (b >= R) {
+                    const float p = __builtin_fmaxf(contrib.x, __builtin_fmaxf(contrib.y, contrib.z));
+                    if (draw(skey, 3 * b + 2) > p) {
+                        done = true;
+                    } else {
+                        contrib = contrib / p;
+                    }
+                }
+                if (!done) {
+                    const f3 o = pos + nrm * kEps;
+                    const f3 d = wi;
+                    ++b;
+                    if (b < B) {
+                        uint32_t dp = 0;
+                        const HitRec h = trace_linear<STATS>(s_sph, a.n_spheres, o, d, dp);
+                        if (STATS) { n_traces++; n_disc += dp; }
+                        if (h.idx >= 0) {
+                            if (STATS) n_hits++;
+                            const float4 sp = s_sph[h.idx];
+                            hit_geometry(sp, o, d, h.t, pos, nrm);
+                            idx = h.idx;
+                        } else {
+                            light = light + sky_eval(a, d) * contrib;
+                            done = true;
+                        }
+                    } else {
+                        done = true;  // bounce budget exhausted: no sky term (integrator.rs:47,92)
+                    }
+                }
+                if (done) {
+                    acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
+                    ++s;
+                    b = 0;
+                    pos = pos0; nrm = nrm0; idx = idx0;
+                    contrib = mk3(1.0f, 1.0f, 1.0f);
+                    light = mk3(0.0f, 0.0f, 0.0f);
+                    skey = sample_key(a.seed_hi, pkey, a.sample_base + s);
+                    if (STATS && s < spp) { n_traces++; n_disc += disc0; n_hits++; }
+                }
+            }
+        }
+    }
+    a.sum[pixel] = acc;
+    a.counts[pixel] += spp;
+
+    if (STATS) {
+        // algorithmic counts, as the reference would execute them (primary ray per sample)
+        atomicAdd(&a.stats[0], (unsigned long long)spp);
+        atomicAdd(&a.stats[1], (unsigned long long)n_traces);
+        atomicAdd(&a.stats[2], (unsigned long long)n_traces * a.n_spheres);
+        atomicAdd(&a.stats[3], (unsigned long long)n_disc);
+        atomicAdd(&a.stats[4], (unsigned long long)n_hits);
+    }
+}
+
+__global__ __launch_bounds__(256) void primary_hits_kernel(const HitsArgs a) {
+    extern __shared__ float4 s_sph[];
+    stage_spheres(s_sph, a.spheres, a.n_spheres);
+    uint32_t x, y;
+    const uint32_t tiles_x = (a.w + kTile - 1) / kTile;
+    if (!lane_pixel(tiles_x, 0u, 1u, a.w, a.h, x, y)) return;
+    const uint32_t pixel = y * a.w + x;
+    Ray r0;
+    if (a.rays) {
+        const float* p = a.rays + 6 * (size_t)pixel;
+        r0.o = mk3(p[0], p[1], p[2]);
+        r0.d = mk3(p[3], p[4], p[5]);
+    } else {
+        r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
+    }
+    uint32_t dp = 0;
+    const HitRec h = trace_linear<false>(s_sph, a.n_spheres, r0.o, r0.d, dp);
+    a.out_idx[pixel] = h.idx;
+    if (a.out_t) a.out_t[pixel] = (h.idx >= 0) ? h.t : -1.0f;  // ray_miss: hit_distance = -1 (integrator.rs:158-164)
+}
+
+// Accumulator::get_argb_pixel (full_buffer.rs:49-65) + convert_to_argb (utils.rs:4-9)
+__device__ __forceinline__ uint32_t to_byte(float c) {
+    // Rust `as u32`: saturating, NaN -> 0
+    float v = c * 255.0f;
+    return (v > 0.0f) ? (uint32_t)__builtin_fminf(v, 4294967040.0f) : 0u;
+}
+__device__ __forceinline__ float tone(float sum, float n) {
+    float a = sum / n;
+    a = a / (a + 1.0f);
+    a = powf(a, 1.0f / 2.2f);
+    a = (a > 0.0f) ? a : 0.0f;  // clamp(0,1); NaN -> 0 like SSE max/min
+    a = (a < 1.0f) ? a : 1.0f;
+    return a;
+}
+__global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__ sum, const uint32_t* __restrict__ counts,
+                                                      uint32_t* __restrict__ argb, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float4 s = sum[i];
+        const uint32_t c = counts[i];
+        const float nf = (float)(c > 1u ? c : 1u);
+        argb[i] = (to_byte(tone(s.w, nf)) << 24) | (to_byte(tone(s.x, nf)) << 16) | (to_byte(tone(s.y, nf)) << 8) |
+                  to_byte(tone(s.z, nf));
+    }
+}
+
+}  // namespace
+
+hipError_t init_kernels() {
+    hipError_t e;
+    const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
+    e = hipFuncSetAttribute((const void*)render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)primary_hits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    return e;
+}
+
+static uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) {
+    return rank < n_tiles ? (n_tiles - rank + world - 1) / world : 0;
+}
+
+hipError_t launch_render(const RenderArgs& a, bool stats, hipStream_t stream) {
+    const uint32_t owned = owned_tiles(a.n_tiles, a.tile_rank, a.tile_world);
+    if (owned == 0 || a.spp == 0) return hipSuccess;
+    const dim3 grid(owned * kBlocksPerTile), block(256);
+    const size_t lds = (size_t)a.n_spheres * sizeof(float4);
+    if (stats) {
+        hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, a);
+    } else {
+        hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_primary_hits(const HitsArgs& a, hipStream_t stream) {
+    const uint32_t tiles = ((a.w + kTile - 1) / kTile) * ((a.h + kTile - 1) / kTile);
+    if (tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(primary_hits_kernel, dim3(tiles * kBlocksPerTile), dim3(256),
+                       (size_t)a.n_spheres * sizeof(float4), stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const float4* sum, const uint32_t* counts, uint32_t* argb, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sum, counts, argb, n);
+    return hipGetLastError();
+}
+
+}  // namespace pt

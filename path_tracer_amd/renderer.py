@@ -1,0 +1,201 @@
+"""insploray::renderer — mirror of reference core-engine/src/renderer.rs.
+
+`RayTracer` keeps the reference's method names and meaning (new/set_active_camera/get_current_size/
+prepare_pixels/render_updated/render/get_output/get_last_render_time, renderer.rs:29-173); the body of `render`
+is one call into the HIP backend instead of the 64x64-tile thread pool.  Extra keyword arguments (spp, device,
+integrator settings, raw radiance / primary-hit readback, partitioning) are additions the reference does not have.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from .cameras import Camera, PinholeCamera
+from .scene import Scene
+
+
+class RayTracer:
+    def __init__(self, width, height, device=None):
+        """RayTracer::new (renderer.rs:29-59).  As in the reference the current size starts at [0, 0] and the
+        default camera is PinholeCamera((0,0,2), 0, 35, 55, [width, height]); integrator = 5 bounces, Russian
+        roulette from bounce 2 (renderer.rs:38-41).  `device` defaults to LOCAL_RANK (one process per GPU)."""
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self._ctx = _capi.ctx_p()
+        _capi.check(None, _capi.lib.ir_create(C.byref(self._ctx), int(device)))
+        self.device = int(device)
+        self.active_camera = PinholeCamera((0.0, 0.0, 2.0), (0.0, 0.0, 0.0), 35.0, 55.0, [width, height])
+        self.bounces = 5
+        self.max_compulsory_bounces = 2
+        self.seed = 0x0123456789ABCDEF
+        self._last_render_time = 0.0
+        self._skybox_token = None
+        self._frame = np.zeros(0, dtype=np.uint32)
+
+    # ------------------------------------------------------------------ reference API
+    def set_active_camera(self, camera):
+        """renderer.rs:61-63"""
+        if not isinstance(camera, Camera):
+            raise TypeError("camera must implement cameras.Camera")
+        self.active_camera = camera
+
+    def get_current_size(self):
+        """renderer.rs:65-67"""
+        w, h = C.c_uint32(), C.c_uint32()
+        _capi.check(self._ctx, _capi.lib.ir_get_size(self._ctx, C.byref(w), C.byref(h)))
+        return [w.value, h.value]
+
+    def prepare_pixels(self, scene, width, height):
+        """renderer.rs:70-72: one more sample per pixel on top of the accumulated ones."""
+        self.render(scene, width, height, True)
+
+    def render_updated(self, scene, width, height):
+        """renderer.rs:75-77: reset the accumulator, then one sample per pixel."""
+        self.render(scene, width, height, False)
+
+    def render(self, scene, width, height, acc, spp=1):
+        """renderer.rs:95-162.  Blocks until the frame is rendered.  `spp` (extension) adds that many samples per
+        pixel in one call; spp=1 is the reference behaviour."""
+        ctx = self._ctx
+        width, height = int(width), int(height)
+        # set_size, renderer.rs:80-93: the camera learns the resolution on every render
+        self.active_camera.set_image_resolutions([width, height])
+        self._upload_scene(scene)
+        self._upload_camera(width, height)
+        _capi.check(ctx, _capi.lib.ir_set_integrator(ctx, int(self.bounces), int(self.max_compulsory_bounces),
+                                                     C.c_uint64(self.seed)))
+        _capi.check(ctx, _capi.lib.ir_render(ctx, width, height, int(spp), 1 if acc else 0))
+        self._last_render_time = _capi.lib.ir_last_render_seconds(ctx)
+
+    def get_output(self):
+        """renderer.rs:164-169: resolved 0xAARRGGBB pixels, row 0 = bottom row (the frontend flips)."""
+        w, h = self.get_current_size()
+        n = w * h
+        if self._frame.size != n:
+            self._frame = np.full(n, 0xFF000000, dtype=np.uint32)  # full_buffer.rs:97-99
+        if n:
+            _capi.check(self._ctx, _capi.lib.ir_get_output_argb(self._ctx, self._frame.ctypes.data_as(_capi.c_u32_p), n))
+        return self._frame
+
+    def get_last_render_time(self):
+        """renderer.rs:171-173, seconds."""
+        return self._last_render_time
+
+    # ------------------------------------------------------------------ extensions
+    def set_integrator(self, bounces=None, max_compulsory_bounces=None, seed=None):
+        if bounces is not None:
+            self.bounces = int(bounces)
+        if max_compulsory_bounces is not None:
+            self.max_compulsory_bounces = int(max_compulsory_bounces)
+        if seed is not None:
+            self.seed = int(seed)
+
+    def set_partition(self, mode, rank, world):
+        _capi.check(self._ctx, _capi.lib.ir_set_partition(self._ctx, int(mode), int(rank), int(world)))
+
+    def get_radiance(self):
+        """Accumulator.framebuffer / sample_counts (full_buffer.rs:7-12): (h, w, 4) f32 sums and (h, w) u32."""
+        w, h = self.get_current_size()
+        s = np.zeros((h, w, 4), dtype=np.float32)
+        c = np.zeros((h, w), dtype=np.uint32)
+        if w * h:
+            _capi.check(self._ctx, _capi.lib.ir_get_radiance(self._ctx, _capi.fptr(s), c.ctypes.data_as(_capi.c_u32_p), w * h))
+        return s, c
+
+    def set_radiance(self, sums, counts):
+        w, h = self.get_current_size()
+        s = np.ascontiguousarray(sums, dtype=np.float32).reshape(h, w, 4)
+        c = np.ascontiguousarray(counts, dtype=np.uint32).reshape(h, w)
+        _capi.check(self._ctx, _capi.lib.ir_set_radiance(self._ctx, _capi.fptr(s), c.ctypes.data_as(_capi.c_u32_p), w * h))
+
+    def get_primary_hits(self, scene=None, width=None, height=None, with_t=False):
+        """Closest-hit sphere index per pixel for the primary rays (-1 = miss), from the device."""
+        if scene is not None:
+            self.active_camera.set_image_resolutions([int(width), int(height)])
+            self._upload_scene(scene)
+            self._upload_camera(int(width), int(height))
+            # size the frame without rendering any sample
+            _capi.check(self._ctx, _capi.lib.ir_render(self._ctx, int(width), int(height), 0, 1))
+        w, h = self.get_current_size()
+        idx = np.zeros((h, w), dtype=np.int32)
+        t = np.zeros((h, w), dtype=np.float32) if with_t else None
+        if w * h:
+            _capi.check(self._ctx, _capi.lib.ir_get_primary_hits(
+                self._ctx, idx.ctypes.data_as(_capi.c_i32_p), _capi.fptr(t) if with_t else None, w * h))
+        return (idx, t) if with_t else idx
+
+    def enable_stats(self):
+        _capi.check(self._ctx, _capi.lib.ir_enable_stats(self._ctx, 1))
+
+    def get_stats(self):
+        out = (C.c_uint64 * 5)()
+        _capi.check(self._ctx, _capi.lib.ir_get_stats(self._ctx, out))
+        return dict(zip(("samples", "traces", "tests", "disc_pos", "hits"), [int(v) for v in out]))
+
+    def last_kernel_ms(self):
+        n = C.c_uint32()
+        ms = _capi.lib.ir_last_kernel_ms(self._ctx, C.byref(n))
+        return ms, n.value
+
+    def samples_accumulated(self):
+        return int(_capi.lib.ir_samples_accumulated(self._ctx))
+
+    def close(self):
+        """Drop for RayTracer (renderer.rs:182-191)."""
+        if getattr(self, "_ctx", None):
+            _capi.lib.ir_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ uploads
+    def _upload_scene(self, scene):
+        if not isinstance(scene, Scene):
+            raise TypeError("scene must be a scene.Scene")
+        ctx = self._ctx
+        xyzr, mid = scene.flat_spheres()
+        xyzr = np.ascontiguousarray(xyzr, dtype=np.float32)
+        mid = np.ascontiguousarray(mid, dtype=np.int32)
+        mats = np.ascontiguousarray(scene.flat_materials(), dtype=np.float32)
+        _capi.check(ctx, _capi.lib.ir_set_materials(ctx, _capi.fptr(mats), mats.shape[0]))
+        _capi.check(ctx, _capi.lib.ir_set_spheres(ctx, _capi.fptr(xyzr), mid.ctypes.data_as(_capi.c_i32_p), xyzr.shape[0]))
+        sky = np.asarray(scene.default_sky_color, dtype=np.float32).reshape(3)
+        _capi.check(ctx, _capi.lib.ir_set_sky_color(ctx, _capi.fptr(np.ascontiguousarray(sky))))
+        box = scene.skybox
+        if box is None:
+            if self._skybox_token is not None:
+                _capi.check(ctx, _capi.lib.ir_set_skybox(ctx, None, 0, 0))
+                self._skybox_token = None
+        else:
+            # the sky image is large; re-upload only when the ExrImage (or its buffer object) was replaced
+            token = (id(box), id(box.pixels_buffer), box.width, box.height, getattr(box, "version", 0))
+            if token != self._skybox_token:
+                buf = np.ascontiguousarray(box.pixels_buffer, dtype=np.float32)
+                _capi.check(ctx, _capi.lib.ir_set_skybox(ctx, _capi.fptr(buf), box.width, box.height))
+                self._skybox_token = token
+
+    def _upload_camera(self, width, height):
+        cam = self.active_camera
+        ctx = self._ctx
+        if isinstance(cam, PinholeCamera):
+            _capi.check(ctx, _capi.lib.ir_set_pinhole(ctx, _capi.fptr(cam.local_to_world), _capi.fptr(cam.position),
+                                                      C.c_float(cam.fov), C.c_float(cam.aspect_ratio)))
+            return
+        if width * height == 0:
+            return
+        # generic `dyn Camera` (cameras/mod.rs:7-17): evaluate get_ray on the host, upload W x H rays
+        if hasattr(cam, "get_rays"):
+            rays = np.ascontiguousarray(cam.get_rays(width, height), dtype=np.float32).reshape(height * width, 6)
+        else:
+            rays = np.zeros((height * width, 6), dtype=np.float32)
+            for y in range(height):
+                for x in range(width):
+                    r = cam.get_ray(x, y)
+                    rays[y * width + x, 0:3] = r.origin
+                    rays[y * width + x, 3:6] = r.direction
+        _capi.check(ctx, _capi.lib.ir_set_primary_rays(ctx, _capi.fptr(rays), width, height))
