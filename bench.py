@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the render path (BASELINE.json metric: Msamples/s, path samples, max depth 8,
+1920x1080).
+
+One "step" = one pass of the hot path over one batch: a full render of config C2 (scene S1
+"default+emitter" with the synthetic 1024x512 EXR-style sky, 1920x1080, 1024 spp, bounces 8, Russian roulette from
+bounce 2, seed 0x0123456789ABCDEF) starting from a reset accumulator.  Inputs (scene, sky, camera) are resident on
+the device before the timed region; the timed region contains the integrator launches (and, for N > 1, the RCCL
+reduce of the partial radiance buffers to rank 0 — the path's one exchange step).
+
+N > 1 (launched by torch.distributed.run, one process per GPU): sample-range partition, every rank renders the whole
+frame for its own 1024 sample indices (weak scaling: per-GPU work fixed), partial sums are reduced over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H, SPP, BOUNCES, RR = 1920, 1080, 1024, 8, 2
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
+
+
+def flops_per_sample(st, n_spheres):
+    """F = 36 + sum over executed bounces [25*T + 5*D + (hit ? 112 : 25)], T = N (linear scan).
+    The bounce that ends in a miss pays 25 (sky lookup + accumulate); hits pay 112."""
+    samples = st["samples"]
+    misses = st["traces"] - st["hits"]
+    total = 36 * samples + 25 * st["tests"] + 5 * st["disc_pos"] + 112 * st["hits"] + 25 * misses
+    return total / samples
+
+
+def cpu_baseline(scene, cam_params, budget_s=12.0):
+    """The oracle (C++ restatement of the reference CPU path; the Rust reference cannot be built here) timed on this
+    box's host cores on a bounded sample of the same workload: full 1920x1080 frame, same scene/seed/depth, fewer spp."""
+    from tests import oracle_lib as O
+    cores = min(16, os.cpu_count() or 1)
+    oc = O.OracleCamera(*cam_params, W, H)
+    # calibrate with 1 spp, then size the sample to about budget_s seconds
+    _, _, t1, _ = O.render(oc, scene, 1, bounces=BOUNCES, rr_start=RR, threads=cores)
+    spp = int(max(1, min(64, budget_s / max(t1, 1e-3))))
+    _, _, t, _ = O.render(oc, scene, spp, bounces=BOUNCES, rr_start=RR, threads=cores)
+    _, _, t4, _ = O.render(oc, scene, max(1, spp // 4), bounces=BOUNCES, rr_start=RR, threads=4)
+    return {
+        "value": W * H * spp / t / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"S1 1920x1080, {spp} spp of the 1024 (same scene/seed/depth 8), 64x64 tiles on {cores} threads; "
+                  f"C++ restatement of the reference integrator, libm math",
+        "reference_shaped_4_threads_Msamples_s": W * H * max(1, spp // 4) / t4 / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (the metric is quoted at 1024)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import path_tracer_amd as pta
+    from path_tracer_amd import _capi, workloads as Wk
+
+    spp = args.spp
+    scene = Wk.scene_s1()
+    cam = Wk.default_camera(W, H)
+    rt = pta.RayTracer(0, 0, device=local_rank)
+    rt.set_active_camera(cam)
+    rt.set_integrator(bounces=BOUNCES, max_compulsory_bounces=RR, seed=Wk.RNG_SEED)
+    # accumulator in torch-owned device memory so that RCCL can reduce it in place
+    sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    counts = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    _capi.check(rt._ctx, _capi.lib.ir_bind_accumulator(rt._ctx, sums.data_ptr(), counts.data_ptr(), W, H))
+    if world > 1:
+        rt.set_partition(_capi.IR_PARTITION_SAMPLES, rank, world)
+
+    kernel_ms = []
+
+    def step():
+        rt.render(scene, W, H, False, spp=spp)  # blocks until the launches are done
+        kernel_ms.append(rt.last_kernel_ms())
+        if world > 1:
+            dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel (render_kernel), rank 0 only
+    out = None
+    if rank == 0:
+        ms = [m for m, _ in kernel_ms]
+        launches = sum(n for _, n in kernel_ms)
+        avg_launch_ms = sum(ms) / max(launches, 1)
+        # algorithmic flops per sample from the kernel's own counters (untimed extra render, same workload)
+        if world > 1:
+            rt.set_partition(_capi.IR_PARTITION_NONE, 0, 1)
+        rt.enable_stats()
+        rt.render(scene, W, H, False, spp=spp)
+        st = rt.get_stats()
+        F = flops_per_sample(st, len(scene.spheres))
+        samples_per_launch = W * H * spp / max(1, kernel_ms[0][1])
+        achieved = samples_per_launch * F / (avg_launch_ms * 1e-3) / 1e12
+        total_samples = world * W * H * spp * args.steps
+        out = {
+            "metric": "Msamples/sec (path samples, max depth 8) at 1920x1080",
+            "value": total_samples / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: scene S1 default+emitter (3 spheres) + synthetic 1024x512 equirect sky, {W}x{H}, "
+                            f"{spp} spp per GPU, bounces {BOUNCES}, rr_start {RR}, linear LDS scan",
+                "partition": "none" if world == 1 else f"sample-range x{world} + RCCL reduce(sum) to rank 0",
+                "seed": hex(Wk.RNG_SEED),
+            },
+            "roofline": {
+                "bound": "valu",
+                "achieved": achieved,
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "traffic": None,
+                "kernel": "render_kernel<false>",
+                "avg_launch_ms": avg_launch_ms,
+                "launches_per_step": kernel_ms[0][1],
+                "algorithmic_flops_per_sample": F,
+                "mean_traces_per_sample": st["traces"] / st["samples"],
+                "note": "FP32 vector peak 157.3 TF assumes FMA; this path is bit-exact (no FMA contraction), so its "
+                        "issue ceiling is 78.6 TF (one flop per lane-op); algorithmic flops count the primary ray "
+                        "per sample although the kernel shares it across the samples of a pixel",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, (cam.position, cam.rotation, cam.focal_length, cam.sensor_size))
+        elif world == 1:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    rt.close()
+
+
+if __name__ == "__main__":
+    main()
