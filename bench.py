@@ -27,16 +27,21 @@ W, H, SPP, BOUNCES, RR = 1920, 1080, 1024, 8, 2
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
 
 
-def flops_per_sample(st, n_spheres):
-    """F = 36 + sum over executed bounces [25*T + 5*D + (hit ? 112 : 25)], T = N (linear scan).
+def flops_per_sample(st, ast=None):
+    """F = 36 + sum over executed bounces [25*T + 5*D + (hit ? 112 : 25)].  Linear scan: T = N.
+    LBVH (`ast` given): the *useful* count, T = leaf tests executed + 24 flop per node slab test.
     The bounce that ends in a miss pays 25 (sky lookup + accumulate); hits pay 112."""
     samples = st["samples"]
     misses = st["traces"] - st["hits"]
-    total = 36 * samples + 25 * st["tests"] + 5 * st["disc_pos"] + 112 * st["hits"] + 25 * misses
+    total = 36 * samples + 5 * st["disc_pos"] + 112 * st["hits"] + 25 * misses
+    if ast is None:
+        total += 25 * st["tests"]
+    else:
+        total += 25 * ast["bvh_leaf_tests"] + 24 * ast["bvh_node_visits"]
     return total / samples
 
 
-def cpu_baseline(scene, cam_params, budget_s=12.0):
+def cpu_baseline(scene, cam_params, budget_s=12.0, max_spp=64):
     """The oracle (C++ restatement of the reference CPU path; the Rust reference cannot be built here) timed on this
     box's host cores on a bounded sample of the same workload: full 1920x1080 frame, same scene/seed/depth, fewer spp."""
     from tests import oracle_lib as O
@@ -44,7 +49,7 @@ def cpu_baseline(scene, cam_params, budget_s=12.0):
     oc = O.OracleCamera(*cam_params, W, H)
     # calibrate with 1 spp, then size the sample to about budget_s seconds
     _, _, t1, _ = O.render(oc, scene, 1, bounces=BOUNCES, rr_start=RR, threads=cores)
-    spp = int(max(1, min(64, budget_s / max(t1, 1e-3))))
+    spp = int(max(1, min(max_spp, budget_s / max(t1, 1e-3))))
     _, _, t, _ = O.render(oc, scene, spp, bounces=BOUNCES, rr_start=RR, threads=cores)
     _, _, t4, _ = O.render(oc, scene, max(1, spp // 4), bounces=BOUNCES, rr_start=RR, threads=4)
     return {
@@ -52,8 +57,8 @@ def cpu_baseline(scene, cam_params, budget_s=12.0):
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"S1 1920x1080, {spp} spp of the 1024 (same scene/seed/depth 8), 64x64 tiles on {cores} threads; "
-                  f"C++ restatement of the reference integrator, libm math",
+        "sample": f"1920x1080, {spp} spp of the workload's (same scene/seed/depth 8), 64x64 tiles on {cores} threads; "
+                  f"C++ restatement of the reference integrator (linear scan), libm math",
         "reference_shaped_4_threads_Msamples_s": W * H * max(1, spp // 4) / t4 / 1e6,
     }
 
@@ -64,7 +69,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (the metric is quoted at 1024)")
+    ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (the metric is quoted at 1024)")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 (default, the metric's config): S1 at 1024 spp; c3: 10k spheres at 256 spp")
+    ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,12 +94,20 @@ def main():
     import path_tracer_amd as pta
     from path_tracer_amd import _capi, workloads as Wk
 
-    spp = args.spp
-    scene = Wk.scene_s1()
-    cam = Wk.default_camera(W, H)
+    if args.workload == "c3":
+        spp = args.spp or 256
+        scene = Wk.scene_s2()
+        cam = Wk.camera_s2(W, H)
+        wl_name = f"C3: scene S2 (10 000 random Lambertian/emissive spheres, constant sky), {W}x{H}, {spp} spp per GPU"
+    else:
+        spp = args.spp or SPP
+        scene = Wk.scene_s1()
+        cam = Wk.default_camera(W, H)
+        wl_name = f"C2: scene S1 default+emitter (3 spheres) + synthetic 1024x512 equirect sky, {W}x{H}, {spp} spp per GPU"
     rt = pta.RayTracer(0, 0, device=local_rank)
     rt.set_active_camera(cam)
     rt.set_integrator(bounces=BOUNCES, max_compulsory_bounces=RR, seed=Wk.RNG_SEED)
+    rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
     # accumulator in torch-owned device memory so that RCCL can reduce it in place
     sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     counts = torch.zeros((H, W), dtype=torch.int32, device="cuda")
@@ -140,7 +156,10 @@ def main():
         rt.enable_stats()
         rt.render(scene, W, H, False, spp=spp)
         st = rt.get_stats()
-        F = flops_per_sample(st, len(scene.spheres))
+        info = rt.get_accel_info()
+        lbvh = info["accel"] == _capi.IR_ACCEL_LBVH
+        ast = rt.get_accel_stats() if lbvh else None
+        F = flops_per_sample(st, ast)
         samples_per_launch = W * H * spp / max(1, kernel_ms[0][1])
         achieved = samples_per_launch * F / (avg_launch_ms * 1e-3) / 1e12
         total_samples = world * W * H * spp * args.steps
@@ -158,8 +177,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: scene S1 default+emitter (3 spheres) + synthetic 1024x512 equirect sky, {W}x{H}, "
-                            f"{spp} spp per GPU, bounces {BOUNCES}, rr_start {RR}, linear LDS scan",
+                "workload": f"{wl_name}, bounces {BOUNCES}, rr_start {RR}, "
+                            + (f"LBVH ({info['nodes']} nodes, depth {info['depth']})" if lbvh else "linear LDS scan"),
                 "partition": "none" if world == 1 else f"sample-range x{world} + RCCL reduce(sum) to rank 0",
                 "seed": hex(Wk.RNG_SEED),
             },
@@ -170,18 +189,20 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                 "traffic": None,
-                "kernel": "render_kernel<false>",
+                "kernel": "render_kernel<%s, false>" % ("lbvh" if lbvh else "linear"),
                 "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": kernel_ms[0][1],
                 "algorithmic_flops_per_sample": F,
                 "mean_traces_per_sample": st["traces"] / st["samples"],
+                "brute_force_equivalent_flops_per_sample": flops_per_sample(st, None),
                 "note": "FP32 vector peak 157.3 TF assumes FMA; this path is bit-exact (no FMA contraction), so its "
                         "issue ceiling is 78.6 TF (one flop per lane-op); algorithmic flops count the primary ray "
                         "per sample although the kernel shares it across the samples of a pixel",
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, (cam.position, cam.rotation, cam.focal_length, cam.sensor_size))
+            out["cpu_baseline"] = cpu_baseline(scene, (cam.position, cam.rotation, cam.focal_length, cam.sensor_size),
+                                               max_spp=64 if args.workload == "c2" else 1)
         elif world == 1:
             out["cpu_baseline"] = None
     if world > 1:

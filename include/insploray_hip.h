@@ -79,8 +79,13 @@ int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h);
 /* IR_SKY_NEAREST reproduces ExrImage::sample (exr.rs:13-24); IR_SKY_BILINEAR is an extension. */
 int ir_set_sky_filter(ir_context* ctx, int filter);
 /* Closest-hit structure: IR_ACCEL_LINEAR = the reference's linear scan (integrator.rs:106-127) over an
- * LDS-staged SoA buffer; IR_ACCEL_LBVH = LBVH whose (t, index) equals the scan's; AUTO picks by count. */
+ * LDS-staged SoA buffer (at most 10 000 spheres); IR_ACCEL_LBVH = linear BVH over the spheres whose (t, index)
+ * equals the scan's bit for bit (leaf tests are the scan's arithmetic, node tests are conservative, ties keep the
+ * lowest index); IR_ACCEL_AUTO (default) = scan below 48 spheres, LBVH from there. */
 int ir_set_accel(ir_context* ctx, int accel);
+/* What the next launch will use for the current scene: *out_accel = IR_ACCEL_LINEAR or IR_ACCEL_LBVH, LBVH node
+ * count and depth (0 for the scan).  Builds the LBVH if it is selected and stale.  Any pointer may be NULL. */
+int ir_get_accel_info(ir_context* ctx, int* out_accel, uint32_t* out_nodes, uint32_t* out_depth);
 
 /* -------------------------------------------------------------------------------------------------
  * Camera.  `dyn Camera` (cameras/mod.rs:7-17) is host code; PinholeCamera is the fast path.
@@ -166,6 +171,9 @@ int ir_bind_accumulator(ir_context* ctx, void* d_sum_rgba, void* d_counts, uint3
  * primary ray even where the kernel shares it between samples of a pixel. */
 int ir_enable_stats(ir_context* ctx, int enable);
 int ir_get_stats(ir_context* ctx, uint64_t out5[5]);
+/* Executed acceleration-structure work of the same render: LBVH node visits and leaf sphere tests (both 0 for the
+ * linear scan).  The primary trace a pixel's samples share is counted once per launch here. */
+int ir_get_accel_stats(ir_context* ctx, uint64_t out2[2]);
 
 /* -------------------------------------------------------------------------------------------------
  * EXR (file_formats/exr.rs:26-49: ExrImage::load_exr_image == exr::read_first_rgba_layer_from_file).

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "ir_set_skybox": (C.c_int, [ctx_p, c_float_p, C.c_uint32, C.c_uint32]),
     "ir_set_sky_filter": (C.c_int, [ctx_p, C.c_int]),
     "ir_set_accel": (C.c_int, [ctx_p, C.c_int]),
+    "ir_get_accel_info": (C.c_int, [ctx_p, C.POINTER(C.c_int), c_u32_p, c_u32_p]),
     "ir_set_pinhole": (C.c_int, [ctx_p, c_float_p, c_float_p, C.c_float, C.c_float]),
     "ir_set_primary_rays": (C.c_int, [ctx_p, c_float_p, C.c_uint32, C.c_uint32]),
     "ir_pinhole_compute": (C.c_int, [c_float_p, c_float_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "ir_bind_accumulator": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "ir_enable_stats": (C.c_int, [ctx_p, C.c_int]),
     "ir_get_stats": (C.c_int, [ctx_p, c_u64_p]),
+    "ir_get_accel_stats": (C.c_int, [ctx_p, c_u64_p]),
     "ir_exr_load": (C.c_int, [C.c_char_p, C.POINTER(c_float_p), c_u32_p, c_u32_p]),
     "ir_exr_last_error": (C.c_char_p, []),
     "ir_exr_save": (C.c_int, [C.c_char_p, c_float_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/insploray_hip.h"
+#include "lbvh.h"
 #include "pt_kernels.h"
 
 namespace {
@@ -44,6 +45,10 @@ struct ir_context {
     bool shade_dirty = true;
     uint32_t n_spheres = 0;
     DeviceBuf d_spheres, d_shade;
+    // LBVH (built on the host at ir_set_spheres / ir_set_accel when the LBVH is the selected structure)
+    DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index;
+    uint32_t bvh_nodes = 0, bvh_depth = 0;
+    bool bvh_valid = false;
     float sky[3] = {0.0f, 0.0f, 0.0f};
     DeviceBuf d_skybox;
     uint32_t sky_w = 0, sky_h = 0;
@@ -180,6 +185,37 @@ int rebuild_shade(ir_context* ctx) {
     return IR_OK;
 }
 
+// Which closest-hit structure the next launch uses.  AUTO: the LDS scan up to kAutoLbvhFrom spheres (for a handful
+// of spheres a tree only adds node tests), the LBVH above; more than kMaxLdsSpheres cannot be staged in LDS at all.
+constexpr uint32_t kAutoLbvhFrom = 48;
+constexpr uint32_t kMaxSpheres = 1u << 24;  // leaf = first * 8 + count must stay a non-negative int32
+int selected_accel(const ir_context* ctx) {
+    if (ctx->n_spheres > pt::kMaxLdsSpheres) return pt::kAccelLbvh;
+    if (ctx->accel == IR_ACCEL_LBVH) return ctx->n_spheres ? pt::kAccelLbvh : pt::kAccelLinear;
+    if (ctx->accel == IR_ACCEL_LINEAR) return pt::kAccelLinear;
+    return ctx->n_spheres >= kAutoLbvhFrom ? pt::kAccelLbvh : pt::kAccelLinear;
+}
+
+int ensure_bvh(ir_context* ctx) {
+    if (selected_accel(ctx) != pt::kAccelLbvh || ctx->bvh_valid) return IR_OK;
+    pt::Lbvh t;
+    pt::build_lbvh(ctx->h_spheres.data(), ctx->n_spheres, t);
+    IR_TRY(upload(ctx, ctx->d_bvh_nodes, t.nodes.data(), t.nodes.size() * sizeof(pt::BvhNode)));
+    IR_TRY(upload(ctx, ctx->d_bvh_spheres, t.leaf_spheres.data(), t.leaf_spheres.size() * sizeof(float)));
+    IR_TRY(upload(ctx, ctx->d_bvh_index, t.leaf_index.data(), t.leaf_index.size() * sizeof(int32_t)));
+    ctx->bvh_nodes = (uint32_t)t.nodes.size();
+    ctx->bvh_depth = t.max_depth;
+    ctx->bvh_valid = true;
+    return IR_OK;
+}
+
+void fill_bvh(const ir_context* ctx, pt::LbvhView& v) {
+    v.nodes = (const float4*)ctx->d_bvh_nodes.p;
+    v.leaf_spheres = (const float4*)ctx->d_bvh_spheres.p;
+    v.leaf_index = (const int*)ctx->d_bvh_index.p;
+    v.n_nodes = ctx->bvh_nodes;
+}
+
 void fill_camera(const ir_context* ctx, pt::CameraBlock& c) {
     for (int i = 0; i < 3; ++i) {
         c.xc[i] = ctx->cam_m[i];
@@ -263,6 +299,7 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_rays);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
     release(ctx->d_stats);
+    release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -282,9 +319,15 @@ int ir_set_stream(ir_context* ctx, void* hip_stream) {
 int ir_set_spheres(ir_context* ctx, const float* spheres_xyzr, const int32_t* material_id, uint32_t n) {
     if (!ctx) return IR_EINVAL;
     if (n && (!spheres_xyzr || !material_id)) return fail(ctx, IR_EINVAL, "ir_set_spheres: NULL array with n=%u", n);
-    if (n > pt::kMaxLdsSpheres)
-        return fail(ctx, IR_ELIMIT, "ir_set_spheres: %u spheres exceed the %u this build stages in LDS", n, pt::kMaxLdsSpheres);
+    if (n > kMaxSpheres) return fail(ctx, IR_ELIMIT, "ir_set_spheres: %u spheres exceed the limit of %u", n, kMaxSpheres);
+    if (n > pt::kMaxLdsSpheres && ctx->accel == IR_ACCEL_LINEAR)
+        return fail(ctx, IR_ELIMIT, "ir_set_spheres: %u spheres exceed the %u the linear scan stages in LDS (use IR_ACCEL_AUTO/LBVH)", n,
+                    pt::kMaxLdsSpheres);
     IR_TRY(use_device(ctx));
+    if (n == ctx->n_spheres && (n == 0 || (memcmp(ctx->h_spheres.data(), spheres_xyzr, (size_t)n * 16) == 0 &&
+                                           memcmp(ctx->h_matid.data(), material_id, (size_t)n * 4) == 0)))
+        return IR_OK;  // unchanged scene (the facade re-sends it on every render): keep device tables and the LBVH
+    ctx->bvh_valid = false;
     ctx->h_spheres.assign(spheres_xyzr, spheres_xyzr + (size_t)n * 4);
     ctx->h_matid.assign(material_id, material_id + n);
     ctx->n_spheres = n;
@@ -341,8 +384,11 @@ int ir_set_sky_filter(ir_context* ctx, int filter) {
 
 int ir_set_accel(ir_context* ctx, int accel) {
     if (!ctx) return IR_EINVAL;
-    if (accel != IR_ACCEL_AUTO && accel != IR_ACCEL_LINEAR)
-        return fail(ctx, IR_EINVAL, "ir_set_accel: mode %d is not supported by this build", accel);
+    if (accel != IR_ACCEL_AUTO && accel != IR_ACCEL_LINEAR && accel != IR_ACCEL_LBVH)
+        return fail(ctx, IR_EINVAL, "ir_set_accel: unknown mode %d", accel);
+    if (accel == IR_ACCEL_LINEAR && ctx->n_spheres > pt::kMaxLdsSpheres)
+        return fail(ctx, IR_ELIMIT, "ir_set_accel: the linear scan stages at most %u spheres in LDS, the scene has %u",
+                    pt::kMaxLdsSpheres, ctx->n_spheres);
     ctx->accel = accel;
     return IR_OK;
 }
@@ -412,6 +458,8 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     IR_TRY(check_camera(ctx, width, height, &rays));
     IR_TRY(rebuild_shade(ctx));
     IR_TRY(ensure(ctx, ctx->d_spheres, 16));
+    IR_TRY(ensure_bvh(ctx));
+    const int accel = selected_accel(ctx);
 
     pt::RenderArgs a;
     memset(&a, 0, sizeof(a));
@@ -437,10 +485,11 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     a.n_tiles = a.tiles_x * ((height + pt::kTile - 1) / pt::kTile);
     a.tile_rank = (ctx->part_mode == IR_PARTITION_TILES) ? ctx->rank : 0;
     a.tile_world = (ctx->part_mode == IR_PARTITION_TILES) ? ctx->world : 1;
+    fill_bvh(ctx, a.bvh);
 
     if (ctx->stats_enabled) {
-        IR_TRY(ensure(ctx, ctx->d_stats, 5 * sizeof(unsigned long long)));
-        IR_HIP(ctx, hipMemsetAsync(ctx->d_stats.p, 0, 5 * sizeof(unsigned long long), ctx->stream));
+        IR_TRY(ensure(ctx, ctx->d_stats, pt::kNumStats * sizeof(unsigned long long)));
+        IR_HIP(ctx, hipMemsetAsync(ctx->d_stats.p, 0, pt::kNumStats * sizeof(unsigned long long), ctx->stream));
         a.stats = (unsigned long long*)ctx->d_stats.p;
     }
 
@@ -458,7 +507,7 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
         const uint32_t now = (spp - done < chunk) ? (spp - done) : chunk;
         a.spp = now;
         a.sample_base = (uint32_t)(base + done);
-        IR_HIP(ctx, pt::launch_render(a, ctx->stats_enabled, ctx->stream));
+        IR_HIP(ctx, pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream));
         done += now;
         ctx->last_launches++;
     }
@@ -541,6 +590,7 @@ int ir_get_primary_hits(ir_context* ctx, int32_t* out_index, float* out_t, size_
     const float* rays = nullptr;
     IR_TRY(check_camera(ctx, w, h, &rays));
     IR_TRY(ensure(ctx, ctx->d_spheres, 16));
+    IR_TRY(ensure_bvh(ctx));
     IR_TRY(ensure(ctx, ctx->d_hit_idx, n * sizeof(int32_t)));
     if (out_t) IR_TRY(ensure(ctx, ctx->d_hit_t, n * sizeof(float)));
     pt::HitsArgs a;
@@ -551,9 +601,10 @@ int ir_get_primary_hits(ir_context* ctx, int32_t* out_index, float* out_t, size_
     a.h = h;
     a.spheres = (const float4*)ctx->d_spheres.p;
     a.n_spheres = ctx->n_spheres;
+    fill_bvh(ctx, a.bvh);
     a.out_idx = (int32_t*)ctx->d_hit_idx.p;
     a.out_t = out_t ? (float*)ctx->d_hit_t.p : nullptr;
-    IR_HIP(ctx, pt::launch_primary_hits(a, ctx->stream));
+    IR_HIP(ctx, pt::launch_primary_hits(a, selected_accel(ctx), ctx->stream));
     IR_HIP(ctx, hipMemcpyAsync(out_index, ctx->d_hit_idx.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (out_t) IR_HIP(ctx, hipMemcpyAsync(out_t, ctx->d_hit_t.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -622,6 +673,30 @@ int ir_get_stats(ir_context* ctx, uint64_t out5[5]) {
     IR_HIP(ctx, hipMemcpyAsync(tmp, ctx->d_stats.p, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 5; ++i) out5[i] = tmp[i];
+    return IR_OK;
+}
+
+int ir_get_accel_stats(ir_context* ctx, uint64_t out2[2]) {
+    if (!ctx) return IR_EINVAL;
+    if (!out2) return fail(ctx, IR_EINVAL, "ir_get_accel_stats: NULL");
+    if (!ctx->stats_valid) return fail(ctx, IR_ESTATE, "ir_get_accel_stats: the last render did not collect statistics");
+    IR_TRY(use_device(ctx));
+    unsigned long long tmp[pt::kNumStats];
+    IR_HIP(ctx, hipMemcpyAsync(tmp, ctx->d_stats.p, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out2[0] = tmp[5];
+    out2[1] = tmp[6];
+    return IR_OK;
+}
+
+int ir_get_accel_info(ir_context* ctx, int* out_accel, uint32_t* out_nodes, uint32_t* out_depth) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    IR_TRY(ensure_bvh(ctx));
+    const int accel = selected_accel(ctx);
+    if (out_accel) *out_accel = (accel == pt::kAccelLbvh) ? IR_ACCEL_LBVH : IR_ACCEL_LINEAR;
+    if (out_nodes) *out_nodes = (accel == pt::kAccelLbvh) ? ctx->bvh_nodes : 0;
+    if (out_depth) *out_depth = (accel == pt::kAccelLbvh) ? ctx->bvh_depth : 0;
     return IR_OK;
 }
 

@@ -1,0 +1,139 @@
+// lbvh.cpp — host LBVH build: 30-bit Morton codes of the sphere centres, sort, top-down split at the highest
+// differing code bit (the tree a Karras radix build produces), leaves of <= kLeafMax spheres, pre-order emission with
+// skip links for stackless traversal.
+#include "lbvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace pt {
+namespace {
+
+uint32_t expand10(uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+struct Builder {
+    const float* s;
+    std::vector<uint32_t> code;
+    std::vector<uint32_t> order;
+    Lbvh* out;
+
+    void bounds(uint32_t first, uint32_t last, float lo[3], float hi[3]) const {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = INFINITY;
+            hi[k] = -INFINITY;
+        }
+        for (uint32_t i = first; i < last; ++i) {
+            const float* p = s + 4 * (size_t)order[i];
+            const float r = std::fabs(p[3]);
+            for (int k = 0; k < 3; ++k) {
+                // one ulp outwards so that c +- r rounding never shrinks the box; non-finite spheres make the box
+                // infinite (always traversed), which keeps the scan's behaviour for them
+                float a = std::nextafter(p[k] - r, -INFINITY), b = std::nextafter(p[k] + r, INFINITY);
+                if (!(a == a) || !(b == b)) {
+                    a = -INFINITY;
+                    b = INFINITY;
+                }
+                lo[k] = std::min(lo[k], a);
+                hi[k] = std::max(hi[k], b);
+            }
+        }
+    }
+
+    // returns the node index
+    uint32_t build(uint32_t first, uint32_t last, int bit, uint32_t depth) {
+        const uint32_t me = (uint32_t)out->nodes.size();
+        out->nodes.emplace_back();
+        out->max_depth = std::max(out->max_depth, depth);
+        BvhNode nd;
+        bounds(first, last, nd.lo, nd.hi);
+        const uint32_t count = last - first;
+        if (count <= kLeafMax) {
+            nd.leaf = (int32_t)(first * 8 + count);
+        } else {
+            nd.leaf = -1;
+            // split at the highest bit (<= bit) in which the first and last code differ
+            uint32_t split = first + count / 2;
+            int b = bit;
+            const uint32_t diff = code[order[first]] ^ code[order[last - 1]];
+            if (diff != 0) {
+                while (b >= 0 && !((diff >> b) & 1u)) --b;
+                // first element whose bit b is set (codes are sorted)
+                uint32_t lo_i = first, hi_i = last - 1;
+                while (lo_i < hi_i) {
+                    const uint32_t mid = (lo_i + hi_i) / 2;
+                    if ((code[order[mid]] >> b) & 1u) hi_i = mid; else lo_i = mid + 1;
+                }
+                split = lo_i;
+                --b;
+            }
+            build(first, split, b, depth + 1);
+            build(split, last, b, depth + 1);
+        }
+        nd.skip = (int32_t)out->nodes.size();
+        out->nodes[me] = nd;
+        return me;
+    }
+};
+
+}  // namespace
+
+void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
+    out.nodes.clear();
+    out.leaf_spheres.clear();
+    out.leaf_index.clear();
+    out.max_depth = 0;
+    if (n == 0) return;
+    Builder b;
+    b.s = spheres_xyzr;
+    b.out = &out;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float c = spheres_xyzr[4 * (size_t)i + k];
+            if (std::isfinite(c)) {
+                lo[k] = std::min(lo[k], c);
+                hi[k] = std::max(hi[k], c);
+            }
+        }
+    b.code.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; ++k) {
+            const float c = spheres_xyzr[4 * (size_t)i + k];
+            const float ext = hi[k] - lo[k];
+            float u = (std::isfinite(c) && ext > 0.0f) ? (c - lo[k]) / ext : 0.0f;
+            u = std::min(std::max(u, 0.0f), 1.0f);
+            q[k] = (uint32_t)std::min(1023.0f, u * 1024.0f);
+        }
+        b.code[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    }
+    b.order.resize(n);
+    std::iota(b.order.begin(), b.order.end(), 0u);
+    std::sort(b.order.begin(), b.order.end(), [&](uint32_t x, uint32_t y) {
+        return b.code[x] != b.code[y] ? b.code[x] < b.code[y] : x < y;
+    });
+    out.nodes.reserve(2 * (size_t)n / 2 + 8);
+    b.build(0, n, 29, 0);
+    out.leaf_spheres.resize((size_t)n * 4);
+    out.leaf_index.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* p = spheres_xyzr + 4 * (size_t)b.order[i];
+        float* o = &out.leaf_spheres[4 * (size_t)i];
+        o[0] = p[0];
+        o[1] = p[1];
+        o[2] = p[2];
+        o[3] = p[3] * p[3];  // radius * radius (integrator.rs:111)
+        out.leaf_index[i] = (int32_t)b.order[i];
+    }
+}
+
+}  // namespace pt

@@ -8,7 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define PT_DEV __device__ __forceinline__
+// __host__ too: tests/cpp/lbvh_check.hip runs the traversal code below on the CPU against the scan
+#define PT_DEV __host__ __device__ __forceinline__
 
 namespace pt {
 
@@ -187,6 +188,75 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
             idx = (int)i;
             best = t;
         }
+    }
+    HitRec h;
+    h.t = best;
+    h.idx = idx;
+    return h;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Closest hit through the LBVH (lbvh.h).  Stackless pre-order traversal with skip links.  Leaf tests are the scan's
+// arithmetic; the accept rule adds "equal t keeps the lower original index", which is what a scan in index order with
+// a strict '<' returns.  Node tests are conservative: each box is inflated by pad = (L1 distance from the ray origin
+// to the farthest box corner) * 2^-7 before the slab test.  That pad dominates (a) the band in which the rounded
+// discriminant of a geometrically missed sphere can still come out >= 0 (sqrt(K*eps)*|oc|, K ~ 64 => 2e-3 |oc|) and
+// (b) the error of the computed root against the geometric entry distance, so no sphere the scan would accept with
+// t <= best is ever pruned.
+// ----------------------------------------------------------------------------------------------------
+struct LbvhView {
+    const float4* __restrict__ nodes;         // 2 x float4 per node: (lo.xyz, skip), (hi.xyz, leaf)
+    const float4* __restrict__ leaf_spheres;  // leaf order: (cx, cy, cz, r*r)
+    const int* __restrict__ leaf_index;       // leaf order -> original sphere index
+    uint32_t n_nodes;
+};
+
+template <bool STATS>
+PT_DEV HitRec trace_lbvh(const LbvhView& v, f3 o, f3 d, uint32_t& disc_pos, uint32_t& node_visits, uint32_t& leaf_tests) {
+    float best = kF32Max;
+    int idx = -1;
+    const float a = dot(d, d);
+    const float a4 = 4.0f * a;
+    const float a2 = 2.0f * a;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;  // +-inf for an axis-parallel ray
+    uint32_t node = 0;
+    while (node < v.n_nodes) {
+        const float4 n0 = v.nodes[2 * node];
+        const float4 n1 = v.nodes[2 * node + 1];
+        if (STATS) node_visits++;
+        const float lx = n0.x - o.x, ly = n0.y - o.y, lz = n0.z - o.z;
+        const float hx = n1.x - o.x, hy = n1.y - o.y, hz = n1.z - o.z;
+        const float pad = (__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)) + __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy)) +
+                           __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * 0.0078125f;
+        const float t1x = (lx - pad) * ix, t2x = (hx + pad) * ix;
+        const float t1y = (ly - pad) * iy, t2y = (hy + pad) * iy;
+        const float t1z = (lz - pad) * iz, t2z = (hz + pad) * iz;
+        // fmin/fmax return the non-NaN operand: a 0*inf slab (origin on the padded plane, d == 0) is unconstrained
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+        const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+        const bool hit = (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= best);
+        const int skip = __builtin_bit_cast(int, n0.w), leaf = __builtin_bit_cast(int, n1.w);
+        if (hit && leaf >= 0) {
+            const uint32_t first = (uint32_t)leaf >> 3, count = (uint32_t)leaf & 7u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 s = v.leaf_spheres[first + k];
+                if (STATS) leaf_tests++;
+                f3 oc = o - mk3(s.x, s.y, s.z);
+                float b = 2.0f * dot(d, oc);
+                float c = dot(oc, oc) - s.w;
+                float disc = b * b - a4 * c;
+                if (disc < 0.0f) continue;
+                if (STATS) disc_pos++;
+                float sq = __builtin_sqrtf(disc);
+                float t = (-b - sq) / a2;
+                const int orig = v.leaf_index[first + k];
+                if (t > 0.0f && (t < best || (t == best && orig < idx))) {
+                    idx = orig;
+                    best = t;
+                }
+            }
+        }
+        node = (hit && leaf < 0) ? node + 1 : (uint32_t)skip;
     }
     HitRec h;
     h.t = best;

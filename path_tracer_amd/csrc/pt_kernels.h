@@ -36,7 +36,9 @@ struct RenderArgs {
     // tile partition: this launch renders tiles t = tile_rank + k * tile_world, k = 0 .. n_owned_tiles-1
     uint32_t tiles_x, n_tiles, tile_rank, tile_world;
 
-    unsigned long long* stats;  // 5 counters or nullptr (only read by the STATS instantiation)
+    LbvhView bvh;  // used by the LBVH instantiation only
+
+    unsigned long long* stats;  // 7 counters or nullptr (only read by the STATS instantiation)
 };
 
 struct HitsArgs {
@@ -45,13 +47,16 @@ struct HitsArgs {
     uint32_t w, h;
     const float4* spheres;
     uint32_t n_spheres;
+    LbvhView bvh;
     int32_t* out_idx;
     float* out_t;  // may be nullptr
 };
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
-hipError_t launch_render(const RenderArgs& a, bool stats, hipStream_t stream);
-hipError_t launch_primary_hits(const HitsArgs& a, hipStream_t stream);
+enum { kAccelLinear = 0, kAccelLbvh = 1 };
+constexpr uint32_t kNumStats = 7;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests
+hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream);
+hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream);
 hipError_t launch_resolve(const float4* sum, const uint32_t* counts, uint32_t* argb, size_t n, hipStream_t stream);
 // one-time per-device kernel attribute setup (dynamic LDS above 64 KiB)
 hipError_t init_kernels();

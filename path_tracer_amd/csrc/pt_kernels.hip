@@ -42,10 +42,32 @@ __device__ __forceinline__ void stage_spheres(float4* s_sph, const float4* __res
     __syncthreads();
 }
 
-template <bool STATS>
+struct WorkCounters {
+    uint32_t disc, nodes, leaves;
+};
+
+// closest hit by the selected structure; centre of sphere idx for closest_hit
+template <int ACCEL, bool STATS, class Args>
+__device__ __forceinline__ HitRec trace_any(const Args& a, const float4* s_sph, f3 o, f3 d, WorkCounters& wc) {
+    if constexpr (ACCEL == kAccelLbvh) {
+        return trace_lbvh<STATS>(a.bvh, o, d, wc.disc, wc.nodes, wc.leaves);
+    } else {
+        return trace_linear<STATS>(s_sph, a.n_spheres, o, d, wc.disc);
+    }
+}
+template <int ACCEL, class Args>
+__device__ __forceinline__ float4 sphere_at(const Args& a, const float4* s_sph, int idx) {
+    if constexpr (ACCEL == kAccelLbvh) {
+        return a.spheres[idx];
+    } else {
+        return s_sph[idx];
+    }
+}
+
+template <int ACCEL, bool STATS>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
-    stage_spheres(s_sph, a.spheres, a.n_spheres);
+    if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
 
     uint32_t x, y;
     if (!lane_pixel(a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
@@ -53,7 +75,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
 
     // per-lane work statistics (STATS only): traces, discriminant >= 0 tests, hits
     uint32_t n_traces = 0, n_disc = 0, n_hits = 0;
-    uint32_t disc0 = 0;
+    WorkCounters wc0 = {0, 0, 0}, wc = {0, 0, 0};
 
     // ---- primary ray + primary closest hit (shared by all samples of the pixel)
     Ray r0;
@@ -73,7 +95,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
             acc.x += 0.0f; acc.y += 0.0f; acc.z += 0.0f; acc.w += 1.0f;
         }
     } else {
-        const HitRec h0 = trace_linear<STATS>(s_sph, a.n_spheres, r0.o, r0.d, disc0);
+        const HitRec h0 = trace_any<ACCEL, STATS>(a, s_sph, r0.o, r0.d, wc0);
+        const uint32_t disc0 = wc0.disc;
         if (h0.idx < 0) {
             // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89)
             f3 light = mk3(0.0f, 0.0f, 0.0f) + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
@@ -87,7 +110,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
         } else {
             f3 pos0, nrm0;
             {
-                const float4 sp = s_sph[h0.idx];
+                const float4 sp = sphere_at<ACCEL>(a, s_sph, h0.idx);
                 hit_geometry(sp, r0.o, r0.d, h0.t, pos0, nrm0);
             }
             const int idx0 = h0.idx;
@@ -125,12 +148,12 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
                     const f3 d = wi;
                     ++b;
                     if (b < B) {
-                        uint32_t dp = 0;
-                        const HitRec h = trace_linear<STATS>(s_sph, a.n_spheres, o, d, dp);
-                        if (STATS) { n_traces++; n_disc += dp; }
+                        const uint32_t before = wc.disc;
+                        const HitRec h = trace_any<ACCEL, STATS>(a, s_sph, o, d, wc);
+                        if (STATS) { n_traces++; n_disc += wc.disc - before; }
                         if (h.idx >= 0) {
                             if (STATS) n_hits++;
-                            const float4 sp = s_sph[h.idx];
+                            const float4 sp = sphere_at<ACCEL>(a, s_sph, h.idx);
                             hit_geometry(sp, o, d, h.t, pos, nrm);
                             idx = h.idx;
                         } else {
@@ -164,12 +187,16 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
         atomicAdd(&a.stats[2], (unsigned long long)n_traces * a.n_spheres);
         atomicAdd(&a.stats[3], (unsigned long long)n_disc);
         atomicAdd(&a.stats[4], (unsigned long long)n_hits);
+        // executed acceleration-structure work (the shared primary trace is counted once per launch)
+        atomicAdd(&a.stats[5], (unsigned long long)wc.nodes + wc0.nodes);
+        atomicAdd(&a.stats[6], (unsigned long long)wc.leaves + wc0.leaves);
     }
 }
 
+template <int ACCEL>
 __global__ __launch_bounds__(256) void primary_hits_kernel(const HitsArgs a) {
     extern __shared__ float4 s_sph[];
-    stage_spheres(s_sph, a.spheres, a.n_spheres);
+    if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
     uint32_t x, y;
     const uint32_t tiles_x = (a.w + kTile - 1) / kTile;
     if (!lane_pixel(tiles_x, 0u, 1u, a.w, a.h, x, y)) return;
@@ -182,8 +209,8 @@ __global__ __launch_bounds__(256) void primary_hits_kernel(const HitsArgs a) {
     } else {
         r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
     }
-    uint32_t dp = 0;
-    const HitRec h = trace_linear<false>(s_sph, a.n_spheres, r0.o, r0.d, dp);
+    WorkCounters wc = {0, 0, 0};
+    const HitRec h = trace_any<ACCEL, false>(a, s_sph, r0.o, r0.d, wc);
     a.out_idx[pixel] = h.idx;
     if (a.out_t) a.out_t[pixel] = (h.idx >= 0) ? h.t : -1.0f;  // ray_miss: hit_distance = -1 (integrator.rs:158-164)
 }
@@ -220,11 +247,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
 hipError_t init_kernels() {
     hipError_t e;
     const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
-    e = hipFuncSetAttribute((const void*)render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)primary_hits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute((const void*)primary_hits_kernel<kAccelLinear>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     return e;
 }
 
@@ -232,24 +259,36 @@ static uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) {
     return rank < n_tiles ? (n_tiles - rank + world - 1) / world : 0;
 }
 
-hipError_t launch_render(const RenderArgs& a, bool stats, hipStream_t stream) {
+hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream) {
     const uint32_t owned = owned_tiles(a.n_tiles, a.tile_rank, a.tile_world);
     if (owned == 0 || a.spp == 0) return hipSuccess;
     const dim3 grid(owned * kBlocksPerTile), block(256);
-    const size_t lds = (size_t)a.n_spheres * sizeof(float4);
-    if (stats) {
-        hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, a);
+    if (accel == kAccelLbvh) {
+        if (stats) {
+            hipLaunchKernelGGL((render_kernel<kAccelLbvh, true>), grid, block, 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((render_kernel<kAccelLbvh, false>), grid, block, 0, stream, a);
+        }
     } else {
-        hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, stream, a);
+        const size_t lds = (size_t)a.n_spheres * sizeof(float4);
+        if (stats) {
+            hipLaunchKernelGGL((render_kernel<kAccelLinear, true>), grid, block, lds, stream, a);
+        } else {
+            hipLaunchKernelGGL((render_kernel<kAccelLinear, false>), grid, block, lds, stream, a);
+        }
     }
     return hipGetLastError();
 }
 
-hipError_t launch_primary_hits(const HitsArgs& a, hipStream_t stream) {
+hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream) {
     const uint32_t tiles = ((a.w + kTile - 1) / kTile) * ((a.h + kTile - 1) / kTile);
     if (tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(primary_hits_kernel, dim3(tiles * kBlocksPerTile), dim3(256),
-                       (size_t)a.n_spheres * sizeof(float4), stream, a);
+    if (accel == kAccelLbvh) {
+        hipLaunchKernelGGL(primary_hits_kernel<kAccelLbvh>, dim3(tiles * kBlocksPerTile), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(primary_hits_kernel<kAccelLinear>, dim3(tiles * kBlocksPerTile), dim3(256),
+                           (size_t)a.n_spheres * sizeof(float4), stream, a);
+    }
     return hipGetLastError();
 }
 

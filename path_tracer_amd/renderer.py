@@ -94,6 +94,15 @@ class RayTracer:
     def set_partition(self, mode, rank, world):
         _capi.check(self._ctx, _capi.lib.ir_set_partition(self._ctx, int(mode), int(rank), int(world)))
 
+    def set_accel(self, accel):
+        """IR_ACCEL_AUTO / IR_ACCEL_LINEAR (reference scan, integrator.rs:106-127) / IR_ACCEL_LBVH."""
+        _capi.check(self._ctx, _capi.lib.ir_set_accel(self._ctx, int(accel)))
+
+    def get_accel_info(self):
+        a, n, d = C.c_int(), C.c_uint32(), C.c_uint32()
+        _capi.check(self._ctx, _capi.lib.ir_get_accel_info(self._ctx, C.byref(a), C.byref(n), C.byref(d)))
+        return {"accel": a.value, "nodes": n.value, "depth": d.value}
+
     def get_radiance(self):
         """Accumulator.framebuffer / sample_counts (full_buffer.rs:7-12): (h, w, 4) f32 sums and (h, w) u32."""
         w, h = self.get_current_size()
@@ -132,6 +141,11 @@ class RayTracer:
         out = (C.c_uint64 * 5)()
         _capi.check(self._ctx, _capi.lib.ir_get_stats(self._ctx, out))
         return dict(zip(("samples", "traces", "tests", "disc_pos", "hits"), [int(v) for v in out]))
+
+    def get_accel_stats(self):
+        out = (C.c_uint64 * 2)()
+        _capi.check(self._ctx, _capi.lib.ir_get_accel_stats(self._ctx, out))
+        return {"bvh_node_visits": int(out[0]), "bvh_leaf_tests": int(out[1])}
 
     def last_kernel_ms(self):
         n = C.c_uint32()

@@ -53,17 +53,70 @@ def test_primary_hits_bit_identical_s1(pta, tracer, oracle, w, h):
         assert set(np.unique(idx)) >= {-1, 1}
 
 
-def test_primary_hits_bit_identical_10k(pta, tracer, oracle):
-    from path_tracer_amd import workloads as W
+@pytest.mark.parametrize("accel", ["linear", "lbvh"])
+def test_primary_hits_bit_identical_10k(pta, tracer, oracle, accel):
+    """C3 scene: the LDS-staged scan and the LBVH both return the reference scan's (index, t) bit for bit."""
+    from path_tracer_amd import _capi, workloads as W
     w, h = 480, 270
     scene = W.scene_s2()
     cam = W.camera_s2(w, h)
     tracer.set_active_camera(cam)
-    idx, t = tracer.get_primary_hits(scene, w, h, with_t=True)
+    tracer.set_accel(_capi.IR_ACCEL_LINEAR if accel == "linear" else _capi.IR_ACCEL_LBVH)
+    try:
+        idx, t = tracer.get_primary_hits(scene, w, h, with_t=True)
+        info = tracer.get_accel_info()
+    finally:
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    assert info["accel"] == (_capi.IR_ACCEL_LINEAR if accel == "linear" else _capi.IR_ACCEL_LBVH)
     oidx, ot = oracle.primary_hits(oracle.camera_from(cam, w, h), scene)
     assert idx.tobytes() == oidx.tobytes()
     assert t.tobytes() == ot.tobytes()
     assert len(np.unique(idx)) > 100
+
+
+@pytest.mark.parametrize("accel", ["linear", "lbvh"])
+def test_radiance_bit_exact_10k(pta, tracer, oracle, accel):
+    """Bounce rays (non-unit directions, origins on sphere surfaces) through both structures == oracle scan."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = 96, 54, 4
+    scene = W.scene_s2()
+    cam = W.camera_s2(w, h)
+    _setup(pta, tracer, scene, cam, 8, 2)
+    tracer.set_accel(_capi.IR_ACCEL_LINEAR if accel == "linear" else _capi.IR_ACCEL_LBVH)
+    try:
+        tracer.enable_stats()
+        tracer.render(scene, w, h, False, spp=spp)
+        s, c = tracer.get_radiance()
+        st = tracer.get_stats()
+        ast = tracer.get_accel_stats()
+    finally:
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    os_, oc, _, ost = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=8, rr_start=2, seed=SEED,
+                                    math_mode=1, want_stats=True)
+    assert c.tobytes() == oc.tobytes()
+    assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
+    # algorithmic counters: traces, hits and scan-equivalent tests are structure independent
+    assert {k: st[k] for k in ("samples", "traces", "tests", "hits")} == {k: ost[k] for k in ("samples", "traces", "tests", "hits")}
+    if accel == "linear":
+        assert st["disc_pos"] == ost["disc_pos"] and ast == {"bvh_node_visits": 0, "bvh_leaf_tests": 0}
+    else:
+        assert 0 < ast["bvh_leaf_tests"] < st["tests"] // 50 and ast["bvh_node_visits"] > 0
+
+
+def test_more_spheres_than_lds_holds(pta, tracer, oracle):
+    """20 000 spheres cannot be staged in LDS: AUTO must pick the LBVH, LINEAR must be refused, hits == oracle scan."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h = 160, 90
+    scene = W.scene_s2(n=20000)
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    idx, t = tracer.get_primary_hits(scene, w, h, with_t=True)
+    assert tracer.get_accel_info()["accel"] == _capi.IR_ACCEL_LBVH
+    oidx, ot = oracle.primary_hits(oracle.camera_from(cam, w, h), scene)
+    assert idx.tobytes() == oidx.tobytes() and t.tobytes() == ot.tobytes()
+    with pytest.raises(pta.InsplorayError):
+        tracer.set_accel(_capi.IR_ACCEL_LINEAR)
+    tracer.set_accel(_capi.IR_ACCEL_AUTO)
 
 
 @pytest.mark.parametrize("skybox", ["synthetic", None])
