@@ -175,6 +175,14 @@ int ir_get_stats(ir_context* ctx, uint64_t out5[5]);
  * linear scan).  The primary trace a pixel's samples share is counted once per launch here. */
 int ir_get_accel_stats(ir_context* ctx, uint64_t out2[2]);
 
+/* Self test of the arithmetic contract (no counterpart in the reference).  The kernels replace hipcc's long IEEE
+ * f32 sqrt / divide expansions by short sequences that return the same correctly rounded bits; this runs, on the
+ * context's GPU, the exhaustive (all 2^32 inputs) and randomised (2^log2_random_samples cases) comparisons against
+ * the IEEE expansions and fills 10 mismatch counters, all of which must be 0:
+ *   [0] sqrt  [1] 1/sqrt (two roundings)  [2] 1/x  [3] x/PI  [4] x/2PI  [5] (x-1)/(x+1) of the atan kernel
+ *   [6] a/b pairs  [7] (brdf*cos)/(cos/PI) weights  [8] contribution/p  [9] one-divide closest-hit scan vs literal scan */
+int ir_selftest_exact_math(ir_context* ctx, uint64_t* out_mismatches, uint32_t n_out, uint32_t log2_random_samples);
+
 /* -------------------------------------------------------------------------------------------------
  * EXR (file_formats/exr.rs:26-49: ExrImage::load_exr_image == exr::read_first_rgba_layer_from_file).
  * From-scratch reader: single/multi-part, scanline and tiled (level 0) files, HALF/FLOAT/UINT channels,

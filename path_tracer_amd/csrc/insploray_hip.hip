@@ -43,6 +43,7 @@ struct ir_context {
     std::vector<int32_t> h_matid;   // n
     std::vector<float> h_materials; // m x 9
     bool shade_dirty = true;
+    bool fast_materials = false;
     uint32_t n_spheres = 0;
     DeviceBuf d_spheres, d_shade;
     // LBVH (built on the host at ir_set_spheres / ir_set_accel when the LBVH is the selected structure)
@@ -169,6 +170,7 @@ int rebuild_shade(ir_context* ctx) {
     const uint32_t m = (uint32_t)(ctx->h_materials.size() / 9);
     std::vector<float> t((size_t)n * 8 + 8, 0.0f);
     static const float def[9] = {1.0f, 1.0f, 1.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool fast = true;
     for (uint32_t i = 0; i < n; ++i) {
         const int32_t id = ctx->h_matid[i];
         const float* mt = (id < 0 || (uint32_t)id >= m) ? def : &ctx->h_materials[(size_t)id * 9];
@@ -176,12 +178,19 @@ int rebuild_shade(ir_context* ctx) {
         o[0] = mt[0] / pt::kPi;
         o[1] = mt[1] / pt::kPi;
         o[2] = mt[2] / pt::kPi;
+        for (int k = 0; k < 3; ++k) {
+            uint32_t bits;
+            memcpy(&bits, &o[k], 4);
+            // +0, or 2^-30 <= brdf < 2^30 (rejects negatives, -0, denormals, inf, NaN): pt_device.h scatter_weight
+            if (!(bits == 0u || (bits - (97u << 23)) < (60u << 23))) fast = false;
+        }
         o[4] = mt[5] * mt[8];
         o[5] = mt[6] * mt[8];
         o[6] = mt[7] * mt[8];
     }
     IR_TRY(upload(ctx, ctx->d_shade, t.data(), t.size() * sizeof(float)));
     ctx->shade_dirty = false;
+    ctx->fast_materials = fast;
     return IR_OK;
 }
 
@@ -470,6 +479,7 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     a.spheres = (const float4*)ctx->d_spheres.p;
     a.shade = (const float4*)ctx->d_shade.p;
     a.n_spheres = ctx->n_spheres;
+    a.fast_materials = ctx->fast_materials ? 1u : 0u;
     memcpy(a.sky, ctx->sky, sizeof(a.sky));
     a.skybox = (const float4*)ctx->d_skybox.p;
     a.sky_w = ctx->sky_w;
@@ -698,6 +708,28 @@ int ir_get_accel_info(ir_context* ctx, int* out_accel, uint32_t* out_nodes, uint
     if (out_nodes) *out_nodes = (accel == pt::kAccelLbvh) ? ctx->bvh_nodes : 0;
     if (out_depth) *out_depth = (accel == pt::kAccelLbvh) ? ctx->bvh_depth : 0;
     return IR_OK;
+}
+
+int ir_selftest_exact_math(ir_context* ctx, uint64_t* out_mismatches, uint32_t n_out, uint32_t log2_random_samples) {
+    if (!ctx) return IR_EINVAL;
+    if (!out_mismatches || n_out != pt::kNumSelftests)
+        return fail(ctx, IR_EINVAL, "ir_selftest_exact_math: out must hold exactly %u counters", pt::kNumSelftests);
+    if (log2_random_samples < 21 || log2_random_samples > 40)
+        return fail(ctx, IR_EINVAL, "ir_selftest_exact_math: log2_random_samples %u not in [21, 40]", log2_random_samples);
+    IR_TRY(use_device(ctx));
+    DeviceBuf bad;
+    IR_TRY(ensure(ctx, bad, pt::kNumSelftests * sizeof(unsigned long long)));
+    int rc = IR_OK;
+    unsigned long long tmp[pt::kNumSelftests];
+    hipError_t e = hipMemsetAsync(bad.p, 0, sizeof(tmp), ctx->stream);
+    if (e == hipSuccess) e = pt::launch_selftest((unsigned long long*)bad.p, log2_random_samples, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp, bad.p, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, IR_EDEVICE, "ir_selftest_exact_math: %s", hipGetErrorString(e));
+    release(bad);
+    if (rc == IR_OK)
+        for (uint32_t i = 0; i < pt::kNumSelftests; ++i) out_mismatches[i] = tmp[i];
+    return rc;
 }
 
 void ir_free(void* p) { free(p); }

@@ -32,7 +32,86 @@ PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
 PT_DEV f3 cross(f3 a, f3 b) {  // glam vec3.rs
     return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
-PT_DEV f3 normalize(f3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }  // glam: v * length_recip()
+
+// ----------------------------------------------------------------------------------------------------
+// Correctly rounded f32 sqrt / reciprocal / divide in few instructions.
+//
+// hipcc expands an IEEE f32 sqrt into ~20 and a divide into ~12 issue slots (range scaling, v_div_scale/fmas/fixup,
+// +-1 ulp probing, hazard nops); those expansions were ~45 % of the integrator's VALU stream.  For operands in the
+// mid range [2^-63, 2^64) the sequences below return the SAME correctly rounded bits:
+//   sqrt_seq : y = rsq(x); s0 = x*y; s = fma(fma(-s0,s0,x), y/2, s0)           exhaustive over every f32 in range
+//   rcp_seq  : y0 = rcp(b); y = fma(fma(-b,y0,1), y0, y0)                       exhaustive, both signs
+//   x / c    : q = x*RN(1/c); q' = fma(fma(-q,c,x), RN(1/c), q), c = PI, 2PI    exhaustive, both signs and +0
+//   div_seq  : y = RN(1/b); q = a*y; two Markstein steps q <- fma(fma(-b,q,a), y, q).  After the first step q is
+//              within (1/2 + 2^-23) ulp of a/b, i.e. faithful, and a faithful quotient refined with the correctly
+//              rounded reciprocal rounds correctly (Markstein 1990).  Needs the residuals exact and nothing
+//              under/overflowing: b in the mid range, a == +0 or 2^-100 <= |a| < 2^64, 2^-100 <= |a/b| < 2^100.
+// tools/exact_math_check.hip is the search harness; ir_selftest_exact_math re-proves every use below on the device
+// the library runs on (tests/test_gpu_exact_math.py).  Callers branch per WAVE: the sequence is taken only if every
+// active lane's operands are in range (one scalar branch on a ballot), otherwise the whole wave evaluates the plain
+// IEEE expression, so results never depend on which path ran.  Host builds (tests/cpp) use the IEEE expression.
+// ----------------------------------------------------------------------------------------------------
+PT_DEV uint32_t f32_bits(float x) { return __builtin_bit_cast(uint32_t, x); }
+// lo <= x < hi for positive normal lo, hi given by their biased exponents: false for 0, negatives, denormals, inf,
+// NaN.  One subtract + one unsigned compare.
+template <uint32_t ELO, uint32_t EHI>
+PT_DEV bool in_pow2_range(float x) { return (f32_bits(x) - (ELO << 23)) < ((EHI - ELO) << 23); }
+PT_DEV bool mid_range(float x) { return in_pow2_range<64, 191>(x); }  // 2^-63 <= x < 2^64
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_FAST_MATH 1
+PT_DEV bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+PT_DEV float sqrt_seq(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y;
+    const float h = 0.5f * y;
+    const float r = __builtin_fmaf(-s0, s0, x);
+    return __builtin_fmaf(r, h, s0);
+}
+PT_DEV float rcp_seq(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+PT_DEV float div_seq(float a, float b, float y) {  // y = rcp_seq(b)
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y, q1);
+}
+template <int TWO_PI>
+PT_DEV float div_const_seq(float x) {  // x / PI or x / (2 PI); x == +0 or 2^-63 <= |x| < 2^64
+    constexpr float c = TWO_PI ? kTwoPi : kPi;
+    constexpr float ic = TWO_PI ? 0.15915494309189535f : 0.3183098861837907f;  // RN(1/c)
+    const float q = x * ic;
+    const float r = __builtin_fmaf(-q, c, x);
+    return __builtin_fmaf(r, ic, q);
+}
+#else
+#define PT_FAST_MATH 0
+// host pass: the same names as plain IEEE expressions (kernel bodies are parsed for the host too)
+PT_DEV bool wave_all(bool ok) { return ok; }
+PT_DEV float sqrt_seq(float x) { return __builtin_sqrtf(x); }
+PT_DEV float rcp_seq(float b) { return 1.0f / b; }
+PT_DEV float div_seq(float a, float b, float) { return a / b; }
+template <int TWO_PI>
+PT_DEV float div_const_seq(float x) { return x / (TWO_PI ? kTwoPi : kPi); }
+#endif
+
+PT_DEV float sqrt_cr(float x) {  // == sqrtf(x) for every x
+#if PT_FAST_MATH
+    if (__builtin_expect(wave_all(mid_range(x)), 1)) return sqrt_seq(x);
+#endif
+    return __builtin_sqrtf(x);
+}
+PT_DEV float rcp_sqrt_cr(float x) {  // == 1.0f / sqrtf(x) (two roundings: glam length_recip) for every x
+#if PT_FAST_MATH
+    if (__builtin_expect(wave_all(mid_range(x)), 1)) return rcp_seq(sqrt_seq(x));  // sqrt lands in [2^-32, 2^32]
+#endif
+    return 1.0f / __builtin_sqrtf(x);
+}
+PT_DEV f3 normalize(f3 a) { return a * rcp_sqrt_cr(dot(a, a)); }  // glam: v * length_recip()
 
 // ----------------------------------------------------------------------------------------------------
 // Counter-based RNG (replaces rand::ThreadRng, sampler.rs:4-6,21-28).
@@ -88,8 +167,8 @@ PT_DEV float asin_core(float a) {  // |a| <= 0.5
 }
 PT_DEV float acos_poly(float x) {
     const float PIO2 = 1.5707963267948966f;
-    if (x > 0.5f) return 2.0f * asin_core(__builtin_sqrtf(0.5f * (1.0f - x)));
-    if (x < -0.5f) return kPi - 2.0f * asin_core(__builtin_sqrtf(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin_core(sqrt_cr(0.5f * (1.0f - x)));
+    if (x < -0.5f) return kPi - 2.0f * asin_core(sqrt_cr(0.5f * (1.0f + x)));
     return PIO2 - asin_core(x);
 }
 PT_DEV float atan_pos(float x) {  // x >= 0
@@ -97,10 +176,18 @@ PT_DEV float atan_pos(float x) {  // x >= 0
     float y;
     if (x > 2.414213562373095f) {
         y = PIO2;
+#if PT_FAST_MATH
+        if (__builtin_expect(wave_all(x < 1.8446744e+19f), 1)) x = -rcp_seq(x); else  // 2.41 < x < 2^64
+#endif
         x = -(1.0f / x);
     } else if (x > 0.4142135623730950f) {
         y = PIO4;
+#if PT_FAST_MATH
+        // numerator +0 or 2^-24 <= |x - 1| <= 1.42, denominator in [1.41, 3.42]: always inside div_seq's domain
+        { const float den = x + 1.0f; x = div_seq(x - 1.0f, den, rcp_seq(den)); }
+#else
         x = (x - 1.0f) / (x + 1.0f);
+#endif
     } else {
         y = 0.0f;
     }
@@ -167,8 +254,9 @@ struct HitRec {
     int idx;  // -1 = miss
 };
 
+// The scan exactly as written in the reference: one divide per candidate root.
 template <bool STATS>
-PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f3 d, uint32_t& disc_pos) {
+PT_DEV HitRec trace_linear_ieee(const float4* __restrict__ s_sph, uint32_t n, f3 o, f3 d, uint32_t& disc_pos) {
     float best = kF32Max;
     int idx = -1;
     const float a = dot(d, d);
@@ -182,7 +270,7 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
         float disc = b * b - a4 * c;
         if (disc < 0.0f) continue;
         if (STATS) disc_pos++;
-        float sq = __builtin_sqrtf(disc);
+        float sq = sqrt_cr(disc);
         float t = (-b - sq) / a2;
         if (t > 0.0f && t < best) {
             idx = (int)i;
@@ -192,6 +280,58 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
     HitRec h;
     h.t = best;
     h.idx = idx;
+    return h;
+}
+
+// Same result with ONE divide per ray.  t_i = RN(num_i / 2a) with num_i = -b_i - sqrt(disc_i) and a common
+// denominator 2a > 0, and x -> RN(x / 2a) is monotone, so the scan's winner (smallest t, lowest index among equal t)
+// is the sphere with the smallest positive numerator (lowest index among equal numerators) — unless a second,
+// different numerator is so close that both may round to the same t, or t leaves (2^-100, f32::MAX) (underflow to
+// 0, a == 0, overflow, NaN).  Those rays (a wave-uniform branch, practically never taken) rerun the literal scan.
+template <bool STATS>
+PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f3 d, uint32_t& disc_pos) {
+    const float kInf = __builtin_inff();
+    float nmin = kInf, nsecond = kInf;  // smallest / second smallest positive numerator (with multiplicity)
+    int idx = -1;
+    const float a = dot(d, d);
+    const float a4 = 4.0f * a;
+    const float a2 = 2.0f * a;
+    uint32_t dp = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float4 s = s_sph[i];
+        f3 oc = o - mk3(s.x, s.y, s.z);
+        float b = 2.0f * dot(d, oc);
+        float c = dot(oc, oc) - s.w;
+        float disc = b * b - a4 * c;
+        if (disc < 0.0f) continue;
+        if (STATS) dp++;
+        const float num = -b - sqrt_cr(disc);
+        if (num > 0.0f) {
+            nsecond = __builtin_fminf(nsecond, __builtin_fmaxf(nmin, num));
+            if (num < nmin) {
+                nmin = num;
+                idx = (int)i;
+            }
+        }
+    }
+    HitRec h;
+    h.t = kF32Max;
+    h.idx = -1;
+    bool redo = false;
+    if (idx >= 0) {
+        const float t = nmin / a2;
+        h.t = t;
+        h.idx = idx;
+        // 1 + 2^-21: two numerators further apart than 4 ulp cannot round to the same normal quotient
+        redo = !(t > 7.8886090522101181e-31f && t < kF32Max) || (nsecond != nmin && !(nsecond > nmin * 1.000000476837158203125f));
+    }
+    if (__builtin_expect(!wave_all(!redo), 0)) {
+        if (redo) {
+            uint32_t ignored = 0;
+            h = trace_linear_ieee<false>(s_sph, n, o, d, ignored);
+        }
+    }
+    if (STATS) disc_pos += dp;
     return h;
 }
 
@@ -247,7 +387,7 @@ PT_DEV HitRec trace_lbvh(const LbvhView& v, f3 o, f3 d, uint32_t& disc_pos, uint
                 float disc = b * b - a4 * c;
                 if (disc < 0.0f) continue;
                 if (STATS) disc_pos++;
-                float sq = __builtin_sqrtf(disc);
+                float sq = sqrt_cr(disc);
                 float t = (-b - sq) / a2;
                 const int orig = v.leaf_index[first + k];
                 if (t > 0.0f && (t < best || (t == best && orig < idx))) {
@@ -276,7 +416,7 @@ PT_DEV void hit_geometry(float4 sph, f3 o, f3 d, float t, f3& pos, f3& nrm) {
 // sampler.rs:8-18,43-53
 PT_DEV f3 sample_hemisphere(f3 n, float r1, float r2) {
     float phi = kTwoPi * r1;
-    float r = __builtin_sqrtf(r2);
+    float r = sqrt_cr(r2);
     float sn, cs;
     sincos_poly(phi, sn, cs);
     f3 local = mk3(r * cs, r * sn, 1.0f - r);
@@ -301,8 +441,14 @@ PT_DEV void sky_uv(f3 dir, float& u, float& v) {
     cy = (cy > 1.0f) ? 1.0f : cy;
     float theta = acos_poly(cy);
     float phi = atan2_poly(d.z, d.x);
+#if PT_FAST_MATH
+    // phi + PI is +0 or in [2^-23, 6.29]; theta is +0 or in [2^-13, 3.15] (acos_poly): inside div_const_seq's domain
+    u = div_const_seq<1>(phi + kPi);
+    v = div_const_seq<0>(theta);
+#else
     u = (phi + kPi) / kTwoPi;
     v = theta / kPi;
+#endif
 }
 PT_DEV f3 sky_nearest(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, f3 dir) {
     float u, v;
@@ -311,6 +457,38 @@ PT_DEV f3 sky_nearest(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, 
     uint32_t y = texel_index(v * (float)sh, sh);
     float4 t = sky[(size_t)y * sw + x];
     return mk3(t.x, t.y, t.z);
+}
+
+// integrator.rs:66-70: cos = max(wi.n, 0); pdf = cos / PI; contribution *= (brdf * cos) / pdf.
+// `fast_materials` (host, per scene): every brdf component is +0 or in [2^-30, 2^30], so with cos in [2^-60, 2^60]
+// pdf is in the mid range, brdf*cos is +0 or >= 2^-90 and the quotient (~ albedo) is +0 or in [2^-29, 2^32].
+PT_DEV f3 scatter_weight(f3 brdf, float cos_theta, bool fast_materials) {
+#if PT_FAST_MATH
+    if (__builtin_expect(fast_materials && wave_all(in_pow2_range<67, 187>(cos_theta)), 1)) {
+        const float pdf = div_const_seq<0>(cos_theta);
+        const float y = rcp_seq(pdf);
+        const f3 n = brdf * cos_theta;
+        return mk3(div_seq(n.x, pdf, y), div_seq(n.y, pdf, y), div_seq(n.z, pdf, y));
+    }
+#endif
+    const float pdf = cos_theta / kPi;
+    return brdf * cos_theta / pdf;
+}
+
+// integrator.rs:72-78: contribution /= p with p = max component.  `fast_materials` also promises non-negative
+// albedo, hence contribution components >= +0.  In range: p in [2^-32, 2^32) and every component +0 or >= 2^-68,
+// so each quotient is +0 or in [2^-100, 1].  (bits - 1 maps +0 above every positive float: one unsigned min3.)
+PT_DEV f3 roulette_divide(f3 c, float p, bool fast_materials) {
+#if PT_FAST_MATH
+    const uint32_t ux = f32_bits(c.x) - 1u, uy = f32_bits(c.y) - 1u, uz = f32_bits(c.z) - 1u;
+    const uint32_t uxy = ux < uy ? ux : uy;
+    const uint32_t lowest = uxy < uz ? uxy : uz;
+    if (__builtin_expect(fast_materials && wave_all(in_pow2_range<95, 159>(p) && lowest >= (59u << 23) - 1u), 1)) {
+        const float y = rcp_seq(p);
+        return mk3(div_seq(c.x, p, y), div_seq(c.y, p, y), div_seq(c.z, p, y));
+    }
+#endif
+    return c / p;
 }
 
 }  // namespace pt

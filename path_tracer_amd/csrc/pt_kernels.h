@@ -20,6 +20,9 @@ struct RenderArgs {
     const float4* spheres;      // (cx, cy, cz, r)
     const float4* shade;        // per sphere: [2i] = (brdf.rgb, 0) with brdf = albedo / PI, [2i+1] = (emission*power, 0)
     uint32_t n_spheres;
+    // host promise about the shading table (rebuild_shade): every brdf component is +0 or in [2^-30, 2^30]; lets
+    // the kernel take the short exact divide sequences of pt_device.h (results are the same either way)
+    uint32_t fast_materials;
 
     float sky[3];
     const float4* skybox;  // rgb padded to float4, row 0 first; nullptr => constant sky
@@ -58,6 +61,9 @@ constexpr uint32_t kNumStats = 7;  // samples, traces, tests, disc>=0, hits, bvh
 hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream);
 hipError_t launch_resolve(const float4* sum, const uint32_t* counts, uint32_t* argb, size_t n, hipStream_t stream);
+// exact-math self test (pt_selftest.hip): adds mismatch counts into d_bad[kNumSelftests] (zeroed by the caller)
+constexpr uint32_t kNumSelftests = 10;
+hipError_t launch_selftest(unsigned long long* d_bad, uint32_t log2_random, hipStream_t stream);
 // one-time per-device kernel attribute setup (dynamic LDS above 64 KiB)
 hipError_t init_kernels();
 

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
     }
     float4 acc = a.sum[pixel];
     const uint32_t B = a.bounces, R = a.rr_start, spp = a.spp;
+    const bool fast = a.fast_materials != 0;
 
     if (B == 0) {
         // integrator.rs:47: the bounce loop never runs, every sample is (0,0,0,1)
@@ -132,15 +133,14 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
                 const float r2 = draw(skey, 3 * b + 1);
                 const f3 wi = sample_hemisphere(nrm, r1, r2);
                 const float cos_theta = __builtin_fmaxf(dot(wi, nrm), 0.0f);
-                const float pdf = cos_theta / kPi;
-                contrib = contrib * (mk3(m_brdf.x, m_brdf.y, m_brdf.z) * cos_theta / pdf);
+                contrib = contrib * scatter_weight(mk3(m_brdf.x, m_brdf.y, m_brdf.z), cos_theta, fast);
                 bool done = false;
                 if (b >= R) {
                     const float p = __builtin_fmaxf(contrib.x, __builtin_fmaxf(contrib.y, contrib.z));
                     if (draw(skey, 3 * b + 2) > p) {
                         done = true;
                     } else {
-                        contrib = contrib / p;
+                        contrib = roulette_divide(contrib, p, fast);
                     }
                 }
                 if (!done) {
