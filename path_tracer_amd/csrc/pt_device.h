@@ -165,35 +165,34 @@ PT_DEV float asin_core(float a) {  // |a| <= 0.5
     return ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z +
             1.6666752422e-1f) * z * a + a;
 }
+// acos: the three classic ranges share one asin_core evaluation (same operations per lane as the branchy form:
+// 1 + x == 1 - |x| for x < 0), so a wave pays for one polynomial instead of three divergent ones.
 PT_DEV float acos_poly(float x) {
     const float PIO2 = 1.5707963267948966f;
-    if (x > 0.5f) return 2.0f * asin_core(sqrt_cr(0.5f * (1.0f - x)));
-    if (x < -0.5f) return kPi - 2.0f * asin_core(sqrt_cr(0.5f * (1.0f + x)));
-    return PIO2 - asin_core(x);
+    const float ax = __builtin_fabsf(x);
+    const bool big = ax > 0.5f;
+    float arg = x;
+    if (big) arg = sqrt_cr(0.5f * (1.0f - ax));
+    const float p = asin_core(arg);
+    const float two_p = 2.0f * p;
+    return big ? ((x > 0.5f) ? two_p : kPi - two_p) : PIO2 - p;
 }
+// atan on [0, inf): argument reduction to num/den (x > tan(3pi/8): -1/x; x > tan(pi/8): (x-1)/(x+1); else x/1,
+// which is exact), one divide for all three ranges, one polynomial.
 PT_DEV float atan_pos(float x) {  // x >= 0
     const float PIO2 = 1.5707963267948966f, PIO4 = 0.7853981633974483f;
-    float y;
-    if (x > 2.414213562373095f) {
-        y = PIO2;
+    const bool hi = x > 2.414213562373095f, mid = !hi && (x > 0.4142135623730950f);
+    const float y0 = hi ? PIO2 : (mid ? PIO4 : 0.0f);
+    float q;
 #if PT_FAST_MATH
-        if (__builtin_expect(wave_all(x < 1.8446744e+19f), 1)) x = -rcp_seq(x); else  // 2.41 < x < 2^64
+    const float num = hi ? -1.0f : (mid ? x - 1.0f : x);
+    const float den = hi ? x : (mid ? x + 1.0f : 1.0f);
+    // den in [1, 2^64), num == +0 or |num| >= 2^-100 (x/1 is exact for ANY x: q0 = x, residuals 0)
+    if (__builtin_expect(wave_all(den < 1.8446744e+19f), 1)) q = div_seq(num, den, rcp_seq(den)); else
 #endif
-        x = -(1.0f / x);
-    } else if (x > 0.4142135623730950f) {
-        y = PIO4;
-#if PT_FAST_MATH
-        // numerator +0 or 2^-24 <= |x - 1| <= 1.42, denominator in [1.41, 3.42]: always inside div_seq's domain
-        { const float den = x + 1.0f; x = div_seq(x - 1.0f, den, rcp_seq(den)); }
-#else
-        x = (x - 1.0f) / (x + 1.0f);
-#endif
-    } else {
-        y = 0.0f;
-    }
-    float z = x * x;
-    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
-    return y;
+    q = hi ? -(1.0f / x) : (mid ? (x - 1.0f) / (x + 1.0f) : x);
+    const float z = q * q;
+    return y0 + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * q + q);
 }
 PT_DEV float atan2_poly(float y, float x) {
     float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);

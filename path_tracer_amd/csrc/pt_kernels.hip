@@ -9,6 +9,8 @@
 // The sphere SoA buffer is staged in LDS once per workgroup and read wave-uniformly (LDS broadcast).
 #include "pt_kernels.h"
 
+#include <cstdlib>
+
 namespace pt {
 
 namespace {
@@ -270,7 +272,10 @@ hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t
             hipLaunchKernelGGL((render_kernel<kAccelLbvh, false>), grid, block, 0, stream, a);
         }
     } else {
-        const size_t lds = (size_t)a.n_spheres * sizeof(float4);
+        size_t lds = (size_t)a.n_spheres * sizeof(float4);
+        // occupancy experiments only (tools/): IR_DEBUG_LDS_PAD=<bytes> pads the workgroup's LDS allocation
+        static const size_t pad = getenv("IR_DEBUG_LDS_PAD") ? (size_t)atol(getenv("IR_DEBUG_LDS_PAD")) : 0;
+        if (lds + pad <= kMaxLdsSpheres * sizeof(float4)) lds += pad;
         if (stats) {
             hipLaunchKernelGGL((render_kernel<kAccelLinear, true>), grid, block, lds, stream, a);
         } else {
