@@ -163,6 +163,12 @@ def main():
         samples_per_launch = W * H * spp / max(1, kernel_ms[0][1])
         achieved = samples_per_launch * F / (avg_launch_ms * 1e-3) / 1e12
         total_samples = world * W * H * spp * args.steps
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same launch (C2 at 1024 spp only)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if args.workload == "c2" and spp == SPP and not lbvh and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
         out = {
             "metric": "Msamples/sec (path samples, max depth 8) at 1920x1080",
             "value": total_samples / elapsed / 1e6,
@@ -188,7 +194,9 @@ def main():
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_traffic.json); algorithmic: "
+                                "40 B/pixel accumulator = 83 MB + 16 B per escaping path from the L2/MALL-resident sky",
                 "kernel": "render_kernel<%s, false>" % ("lbvh" if lbvh else "linear"),
                 "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": kernel_ms[0][1],

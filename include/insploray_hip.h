@@ -76,7 +76,9 @@ int ir_set_sky_color(ir_context* ctx, const float rgb[3]);
 /* Scene.skybox = Some(ExrImage{pixels_buffer,width,height}) (exr.rs:6-10): rgb is w*h*3 floats, row-major,
  * row 0 first (exr.rs:38).  rgb == NULL removes the skybox (Scene.skybox = None). */
 int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h);
-/* IR_SKY_NEAREST reproduces ExrImage::sample (exr.rs:13-24); IR_SKY_BILINEAR is an extension. */
+/* IR_SKY_NEAREST (default) reproduces ExrImage::sample (exr.rs:13-24).  IR_SKY_BILINEAR is an extension the
+ * reference does not have: same u, v; texel centres at (i + 0.5) / n, longitude wraps, latitude clamps,
+ * a + (b - a) * t along x then y. */
 int ir_set_sky_filter(ir_context* ctx, int filter);
 /* Closest-hit structure: IR_ACCEL_LINEAR = the reference's linear scan (integrator.rs:106-127) over an
  * LDS-staged SoA buffer (at most 10 000 spheres); IR_ACCEL_LBVH = linear BVH over the spheres whose (t, index)

@@ -288,6 +288,15 @@ inline size_t f32_to_usize(float f) {
     if (f >= 1.8446744073709552e19f) return SIZE_MAX;
     return (size_t)f;
 }
+// Extension switch (not in the reference, which is nearest-only): 1 = bilinear lookup, the build's IR_SKY_BILINEAR.
+// Process-global because it is test infrastructure; set through orc_set_sky_filter before rendering.
+static int g_sky_filter = 0;
+inline int bilinear_cell(float f, float n, float* frac) {
+    float g = f * n - 0.5f;
+    float fl = std::floor(g);
+    *frac = g - fl;
+    return (fl >= -1.0f) ? (int)std::fmin(fl, 1073741824.0f) : -1;
+}
 inline V3 sky_lookup(const Scene& sc, V3 dir, int math_mode) {
     V3 d = normalize(dir);
     float cy = d.y;
@@ -297,6 +306,21 @@ inline V3 sky_lookup(const Scene& sc, V3 dir, int math_mode) {
     float phi = math_mode ? poly_atan2(d.z, d.x) : std::atan2(d.z, d.x);
     float u = (phi + kPi) / (2.0f * kPi);
     float v = theta / kPi;
+    if (g_sky_filter == 1) {
+        float tx, ty;
+        int ix = bilinear_cell(u, (float)sc.sky_w, &tx), iy = bilinear_cell(v, (float)sc.sky_h, &ty);
+        int w = (int)sc.sky_w, h = (int)sc.sky_h;
+        int x0 = ix % w;
+        if (x0 < 0) x0 += w;
+        int x1 = (x0 + 1 == w) ? 0 : x0 + 1;
+        int y0 = iy < 0 ? 0 : (iy > h - 1 ? h - 1 : iy);
+        int y1 = iy + 1 < 0 ? 0 : (iy + 1 > h - 1 ? h - 1 : iy + 1);
+        auto tex = [&](int x, int y) { const float* p = sc.skybox + 3 * ((size_t)y * sc.sky_w + x); return v3(p[0], p[1], p[2]); };
+        V3 a = tex(x0, y0), b = tex(x1, y0), c = tex(x0, y1), e = tex(x1, y1);
+        V3 top = a + (b - a) * tx;
+        V3 bot = c + (e - c) * tx;
+        return top + (bot - top) * ty;
+    }
     size_t x = f32_to_usize(std::floor(u * (float)sc.sky_w)) % sc.sky_w;
     size_t y = f32_to_usize(std::floor(v * (float)sc.sky_h)) % sc.sky_h;
     const float* p = sc.skybox + 3 * (y * sc.sky_w + x);
@@ -510,6 +534,7 @@ void orc_sample_hemisphere(const float n[3], float r1, float r2, int math_mode, 
     out[0] = w.x; out[1] = w.y; out[2] = w.z;
 }
 
+void orc_set_sky_filter(int filter) { g_sky_filter = filter; }
 void orc_sky_lookup(const float* skybox, uint32_t sw, uint32_t sh, const float d[3], int math_mode, float out[3]) {
     Scene sc{};
     sc.skybox = skybox;

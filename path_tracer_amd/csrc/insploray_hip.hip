@@ -386,7 +386,7 @@ int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h) {
 
 int ir_set_sky_filter(ir_context* ctx, int filter) {
     if (!ctx) return IR_EINVAL;
-    if (filter != IR_SKY_NEAREST) return fail(ctx, IR_EINVAL, "ir_set_sky_filter: filter %d is not supported by this build", filter);
+    if (filter != IR_SKY_NEAREST && filter != IR_SKY_BILINEAR) return fail(ctx, IR_EINVAL, "ir_set_sky_filter: unknown filter %d", filter);
     ctx->sky_filter = filter;
     return IR_OK;
 }

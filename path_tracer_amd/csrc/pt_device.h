@@ -458,6 +458,32 @@ PT_DEV f3 sky_nearest(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, 
     return mk3(t.x, t.y, t.z);
 }
 
+// Bilinear equirect lookup (IR_SKY_BILINEAR; the north-star variant, NOT what exr.rs:20-23 does).  Texel centres sit
+// at (i + 0.5) / n; columns wrap around in longitude, rows clamp at the poles; lerp(a, b, t) = a + (b - a) * t,
+// first along x on both rows, then along y.  Same u, v as the nearest lookup.
+PT_DEV int bilinear_cell(float f, float n, float& frac) {
+    const float g = f * n - 0.5f;
+    const float fl = __builtin_floorf(g);
+    frac = g - fl;
+    return (fl >= -1.0f) ? (int)__builtin_fminf(fl, 1073741824.0f) : -1;  // NaN -> -1
+}
+PT_DEV f3 sky_bilinear(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, f3 dir) {
+    float u, v, tx, ty;
+    sky_uv(dir, u, v);
+    const int ix = bilinear_cell(u, (float)sw, tx), iy = bilinear_cell(v, (float)sh, ty);
+    const int w = (int)sw, h = (int)sh;
+    int x0 = ix % w;
+    if (x0 < 0) x0 += w;
+    const int x1 = (x0 + 1 == w) ? 0 : x0 + 1;
+    const int y0 = iy < 0 ? 0 : (iy > h - 1 ? h - 1 : iy);
+    const int y1 = iy + 1 < 0 ? 0 : (iy + 1 > h - 1 ? h - 1 : iy + 1);
+    const float4 a = sky[(size_t)y0 * sw + x0], b = sky[(size_t)y0 * sw + x1];
+    const float4 c = sky[(size_t)y1 * sw + x0], d = sky[(size_t)y1 * sw + x1];
+    const f3 top = mk3(a.x, a.y, a.z) + (mk3(b.x, b.y, b.z) - mk3(a.x, a.y, a.z)) * tx;
+    const f3 bot = mk3(c.x, c.y, c.z) + (mk3(d.x, d.y, d.z) - mk3(c.x, c.y, c.z)) * tx;
+    return top + (bot - top) * ty;
+}
+
 // integrator.rs:66-70: cos = max(wi.n, 0); pdf = cos / PI; contribution *= (brdf * cos) / pdf.
 // `fast_materials` (host, per scene): every brdf component is +0 or in [2^-30, 2^30], so with cos in [2^-60, 2^60]
 // pdf is in the mid range, brdf*cos is +0 or >= 2^-90 and the quotient (~ albedo) is +0 or in [2^-29, 2^32].

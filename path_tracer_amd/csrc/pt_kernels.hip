@@ -17,6 +17,7 @@ namespace {
 
 __device__ __forceinline__ f3 sky_eval(const RenderArgs& a, f3 dir) {
     if (a.skybox) {
+        if (a.sky_filter == 1) return sky_bilinear(a.skybox, a.sky_w, a.sky_h, dir);  // IR_SKY_BILINEAR
         return sky_nearest(a.skybox, a.sky_w, a.sky_h, dir);
     }
     return mk3(a.sky[0], a.sky[1], a.sky[2]);

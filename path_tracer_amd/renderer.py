@@ -98,6 +98,10 @@ class RayTracer:
         """IR_ACCEL_AUTO / IR_ACCEL_LINEAR (reference scan, integrator.rs:106-127) / IR_ACCEL_LBVH."""
         _capi.check(self._ctx, _capi.lib.ir_set_accel(self._ctx, int(accel)))
 
+    def set_sky_filter(self, sky_filter):
+        """IR_SKY_NEAREST (reference, exr.rs:20-23) or IR_SKY_BILINEAR (extension)."""
+        _capi.check(self._ctx, _capi.lib.ir_set_sky_filter(self._ctx, int(sky_filter)))
+
     def get_accel_info(self):
         a, n, d = C.c_int(), C.c_uint32(), C.c_uint32()
         _capi.check(self._ctx, _capi.lib.ir_get_accel_info(self._ctx, C.byref(a), C.byref(n), C.byref(d)))

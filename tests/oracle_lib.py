@@ -41,6 +41,7 @@ lib.orc_trace.argtypes = [_f, C.c_uint32, _f, _f, _f, _f, _f]
 lib.orc_trace.restype = C.c_int32
 lib.orc_sample_hemisphere.argtypes = [_f, C.c_float, C.c_float, C.c_int, _f]
 lib.orc_sky_lookup.argtypes = [_f, C.c_uint32, C.c_uint32, _f, C.c_int, _f]
+lib.orc_set_sky_filter.argtypes = [C.c_int]
 lib.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.orc_rng_draw.restype = C.c_float
 lib.orc_rng_mix32.argtypes = [C.c_uint32]
@@ -176,6 +177,11 @@ def sky_lookup(box, d, math_mode=0):
     buf = np.ascontiguousarray(box.pixels_buffer, dtype=np.float32)
     lib.orc_sky_lookup(_fp(buf), box.width, box.height, _fp(np.ascontiguousarray(d, dtype=np.float32)), math_mode, _fp(out))
     return out
+
+
+def set_sky_filter(f):
+    """0 = nearest (the reference), 1 = bilinear (the build's extension); process-global."""
+    lib.orc_set_sky_filter(int(f))
 
 
 def rng_draw(seed, pixel, sample, k):

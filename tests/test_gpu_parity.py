@@ -135,6 +135,29 @@ def test_radiance_bit_exact_same_stream(pta, tracer, oracle, skybox, bounces, rr
     assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
 
 
+def test_bilinear_sky_bit_exact_same_stream(pta, tracer, oracle):
+    """IR_SKY_BILINEAR (north-star variant; the reference is nearest-only) against the oracle's bilinear switch."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = 160, 90, 16
+    scene = W.scene_s1()
+    cam = W.default_camera(w, h)
+    _setup(pta, tracer, scene, cam, 8, 2)
+    tracer.set_sky_filter(_capi.IR_SKY_BILINEAR)
+    oracle.set_sky_filter(1)
+    try:
+        tracer.render(scene, w, h, False, spp=spp)
+        s, c = tracer.get_radiance()
+        os_, oc, _, _ = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1)
+    finally:
+        tracer.set_sky_filter(_capi.IR_SKY_NEAREST)
+        oracle.set_sky_filter(0)
+    assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
+    tracer.render(scene, w, h, False, spp=spp)
+    s_near, _ = tracer.get_radiance()
+    assert not np.array_equal(s, s_near)  # the switch does something
+    assert rel_rmse(s, s_near) < 0.05     # ... but the image is the same sky
+
+
 def test_radiance_vs_libm_oracle_rel_rmse(pta, tracer, oracle):
     from path_tracer_amd import workloads as W
     w, h, spp = 320, 180, 64

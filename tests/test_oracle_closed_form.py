@@ -178,3 +178,34 @@ def test_rng_uniformity(oracle):
     # lag correlation between consecutive draws of a stream
     a = v.reshape(-1, 6)
     assert abs(np.corrcoef(a[:, 0], a[:, 1])[0, 1]) < 0.05
+
+
+def test_bilinear_sky_extension(oracle):
+    """Oracle's bilinear switch (extension, not reference behaviour): exact at texel centres, linear between them,
+    wraps in longitude, clamps at the poles."""
+    from path_tracer_amd.file_formats import ExrImage
+    w, h = 8, 4
+    img = np.zeros((h, w, 3), dtype=np.float32)
+    img[..., 0] = np.arange(w, dtype=np.float32)[None, :]
+    img[..., 1] = np.arange(h, dtype=np.float32)[:, None]
+    img[..., 2] = 1.0
+    box = ExrImage(img.reshape(-1, 3), w, h)
+
+    def direction(u, v):
+        phi, theta = u * 2.0 * np.pi - np.pi, v * np.pi
+        return np.array([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)], dtype=np.float32)
+
+    oracle.set_sky_filter(1)
+    try:
+        c = oracle.sky_lookup(box, direction((2 + 0.5) / w, (1 + 0.5) / h))       # a texel centre
+        assert np.allclose(c, [2.0, 1.0, 1.0], atol=1e-4)
+        c = oracle.sky_lookup(box, direction(3.0 / w, 2.0 / h))                   # corner of four texels
+        assert np.allclose(c, [2.5, 1.5, 1.0], atol=1e-4)
+        c = oracle.sky_lookup(box, direction(0.02 / w, (1 + 0.5) / h))            # wraps between column w-1 and 0
+        assert np.allclose(c[0], 0.5 * (w - 1) + 0.02 * -(w - 1), atol=2e-2) and abs(c[1] - 1.0) < 1e-4
+        c = oracle.sky_lookup(box, direction((2 + 0.5) / w, 0.01 / h))            # above the first row centre: clamps
+        assert np.allclose(c, [2.0, 0.0, 1.0], atol=1e-4)
+    finally:
+        oracle.set_sky_filter(0)
+    c = oracle.sky_lookup(box, direction(3.0 / w + 1e-3, 2.0 / h + 1e-3))          # nearest again
+    assert np.allclose(c, [3.0, 2.0, 1.0])
