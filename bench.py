@@ -70,8 +70,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (the metric is quoted at 1024)")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
-                    help="c2 (default, the metric's config): S1 at 1024 spp; c3: 10k spheres at 256 spp")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="c2 (default, the metric's config): S1 1920x1080 at 1024 spp; c3: 10k spheres at 256 spp; "
+                         "c4: S1 3840x2160 at 4096 spp; c5: env-lit S1 (no emitter) 1920x1080 at 65536 spp")
+    ap.add_argument("--partition", choices=["samples", "tiles"], default=None,
+                    help="N > 1 only. samples (default for c2/c3/c5): every rank renders the whole frame for its own "
+                         "sample indices, per-GPU spp fixed (weak scaling). tiles (default for c4): 64x64 tiles dealt "
+                         "round-robin, total work fixed (strong scaling). Both end in one RCCL reduce(sum) to rank 0.")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
     args = ap.parse_args()
 
@@ -94,7 +99,19 @@ def main():
     import path_tracer_amd as pta
     from path_tracer_amd import _capi, workloads as Wk
 
-    if args.workload == "c3":
+    global W, H
+    if args.workload == "c4":
+        W, H = 3840, 2160
+        spp = args.spp or 4096
+        scene = Wk.scene_s1()
+        cam = Wk.default_camera(W, H)
+        wl_name = f"C4: scene S1 default+emitter + synthetic sky, {W}x{H}, {spp} spp"
+    elif args.workload == "c5":
+        spp = args.spp or 65536
+        scene = Wk.scene_s1(emitter=False, skybox=Wk.synthetic_sky(sun_scale=4000.0))
+        cam = Wk.default_camera(W, H)
+        wl_name = f"C5: scene S1 without emitter, sun-dominated synthetic sky, {W}x{H}, {spp} spp per GPU"
+    elif args.workload == "c3":
         spp = args.spp or 256
         scene = Wk.scene_s2()
         cam = Wk.camera_s2(W, H)
@@ -112,8 +129,11 @@ def main():
     sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     counts = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     _capi.check(rt._ctx, _capi.lib.ir_bind_accumulator(rt._ctx, sums.data_ptr(), counts.data_ptr(), W, H))
+    partition = args.partition or ("tiles" if args.workload == "c4" else "samples")
     if world > 1:
-        rt.set_partition(_capi.IR_PARTITION_SAMPLES, rank, world)
+        rt.set_partition(_capi.IR_PARTITION_TILES if partition == "tiles" else _capi.IR_PARTITION_SAMPLES, rank, world)
+    # samples: every rank adds `spp` samples to every pixel (work grows with N); tiles: the frame is split (work fixed)
+    work_ranks = world if partition == "samples" else 1
 
     kernel_ms = []
 
@@ -160,9 +180,9 @@ def main():
         lbvh = info["accel"] == _capi.IR_ACCEL_LBVH
         ast = rt.get_accel_stats() if lbvh else None
         F = flops_per_sample(st, ast)
-        samples_per_launch = W * H * spp / max(1, kernel_ms[0][1])
+        samples_per_launch = W * H * spp / max(1, kernel_ms[0][1]) / (world if partition == "tiles" else 1)
         achieved = samples_per_launch * F / (avg_launch_ms * 1e-3) / 1e12
-        total_samples = world * W * H * spp * args.steps
+        total_samples = work_ranks * W * H * spp * args.steps
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same launch (C2 at 1024 spp only)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
@@ -178,14 +198,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if partition == "samples" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{wl_name}, bounces {BOUNCES}, rr_start {RR}, "
                             + (f"LBVH ({info['nodes']} nodes, depth {info['depth']})" if lbvh else "linear LDS scan"),
-                "partition": "none" if world == 1 else f"sample-range x{world} + RCCL reduce(sum) to rank 0",
+                "partition": "none" if world == 1 else (f"sample-range x{world}" if partition == "samples" else
+                                                       f"64x64 tiles round-robin x{world}") + " + RCCL reduce(sum) to rank 0",
                 "seed": hex(Wk.RNG_SEED),
             },
             "roofline": {

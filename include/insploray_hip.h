@@ -116,6 +116,15 @@ int ir_pinhole_get_ray(const float local_to_world[16], const float position[3], 
  * ------------------------------------------------------------------------------------------------- */
 int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory_bounces, uint64_t seed);
 
+/* How one ir_render call of spp samples is accumulated (default 128).  The reference adds ONE sample per render()
+ * call: a zeroed TileAccumulator takes the sample (tile_buffer.rs:24-28) and is merged into the frame,
+ * framebuffer += tile (full_buffer.rs:107-125).  A call with spp > 1 is cut into consecutive blocks of
+ * samples_per_block samples; each block is summed from zero in sample order (the tile accumulator) and the block
+ * sums are merged into the accumulator in block order.  Blocks are independent until the merge, which is what lets
+ * one call fill the GPU.  On a zeroed accumulator a call with spp <= samples_per_block is bit-identical to spp
+ * successive reference-style 1-sample calls. */
+int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);
+
 /* Multi-GPU work split for this context (rank in [0, world)).
  *   IR_PARTITION_TILES  : 64x64 tiles (renderer.rs:105-119) dealt round-robin; this rank renders tile t iff
  *                         t % world == rank and leaves every other pixel's sum/count untouched.
@@ -129,8 +138,8 @@ int ir_set_partition(ir_context* ctx, int mode, uint32_t rank, uint32_t world);
  * Render.  Replaces RayTracer::render(scene, width, height, acc) (renderer.rs:95-162):
  *   - resolution change reallocates and zeroes the accumulator (renderer.rs:80-93);
  *   - accumulate == 0 zeroes it first (renderer.rs:99-103) == render_updated; accumulate != 0 == prepare_pixels;
- *   - spp samples per pixel are added (the reference adds exactly 1 per call; spp = 1 reproduces it),
- *     per pixel in sample order, so sums are bit-identical to spp successive 1-sample calls;
+ *   - spp samples per pixel are added (the reference adds exactly 1 per call; spp = 1 reproduces it) in sample
+ *     blocks, see ir_set_sample_block;
  *   - blocks until the kernels have finished (the reference render() is synchronous).
  * ------------------------------------------------------------------------------------------------- */
 int ir_render(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate);
@@ -158,6 +167,9 @@ double ir_last_render_seconds(const ir_context* ctx);
 double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches);
 /* Samples per pixel accumulated by this context since the last reset. */
 uint32_t ir_samples_accumulated(const ir_context* ctx);
+/* Checkpoint restore: after ir_set_radiance with a stored accumulator, tell the context how many samples per pixel
+ * it holds so that the next accumulate != 0 render continues the counter-based sample sequence behind them. */
+int ir_set_samples_accumulated(ir_context* ctx, uint32_t samples);
 
 /* Device pointers of the accumulator (float4 sum per pixel, u32 count per pixel) for RCCL collectives issued
  * by the caller (torch.distributed).  Valid until the next resolution change / ir_bind_accumulator. */

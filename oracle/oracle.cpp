@@ -291,6 +291,8 @@ inline size_t f32_to_usize(float f) {
 // Extension switch (not in the reference, which is nearest-only): 1 = bilinear lookup, the build's IR_SKY_BILINEAR.
 // Process-global because it is test infrastructure; set through orc_set_sky_filter before rendering.
 static int g_sky_filter = 0;
+// Samples per accumulation block of a multi-sample orc_render call (the build's ir_set_sample_block, default 128).
+static uint32_t g_sample_block = 128;
 inline int bilinear_cell(float f, float n, float* frac) {
     float g = f * n - 0.5f;
     float fl = std::floor(g);
@@ -535,6 +537,7 @@ void orc_sample_hemisphere(const float n[3], float r1, float r2, int math_mode, 
 }
 
 void orc_set_sky_filter(int filter) { g_sky_filter = filter; }
+void orc_set_sample_block(uint32_t n) { g_sample_block = n ? n : 1; }
 void orc_sky_lookup(const float* skybox, uint32_t sw, uint32_t sh, const float d[3], int math_mode, float out[3]) {
     Scene sc{};
     sc.skybox = skybox;
@@ -646,14 +649,23 @@ double orc_render(const float m16[16], const float pos[3], float fov, float aspe
                     uint32_t x = tr.ox + dx, y = tr.oy + dy;
                     uint32_t pixel = y * w + x;
                     float* f = &tr.fb[4 * ((size_t)dy * tr.tw + dx)];
-                    // continue the caller's running sum so that the per-pixel order is sequential
+                    // The reference renders ONE sample per render() call: a zeroed TileAccumulator takes it
+                    // (tile_buffer.rs:24-28) and is merged, framebuffer += tile (full_buffer.rs:107-125).  A call of
+                    // spp samples is restated as consecutive blocks of g_sample_block samples, each block one such
+                    // "call": summed from zero in sample order, then merged into the frame in block order.  On a
+                    // zeroed frame and spp <= block this is exactly spp successive reference calls.
                     const float* g = sum_rgba + 4 * (size_t)pixel;
                     float acc[4] = {g[0], g[1], g[2], g[3]};
-                    for (uint32_t s = 0; s < spp; ++s) {
-                        Sampler smp;
-                        init_sampler(smp, pr, pixel, sample_base + s);
-                        V3 c = radiance(sc, cam, tan_half, pr, x, y, smp, st);
-                        acc[0] += c.x; acc[1] += c.y; acc[2] += c.z; acc[3] += 1.0f;
+                    for (uint32_t s0 = 0; s0 < spp; s0 += g_sample_block) {
+                        float tile[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        const uint32_t s1 = std::min(spp, s0 + g_sample_block);
+                        for (uint32_t s = s0; s < s1; ++s) {
+                            Sampler smp;
+                            init_sampler(smp, pr, pixel, sample_base + s);
+                            V3 c = radiance(sc, cam, tan_half, pr, x, y, smp, st);
+                            tile[0] += c.x; tile[1] += c.y; tile[2] += c.z; tile[3] += 1.0f;
+                        }
+                        for (int k = 0; k < 4; ++k) acc[k] += tile[k];
                     }
                     f[0] = acc[0]; f[1] = acc[1]; f[2] = acc[2]; f[3] = acc[3];
                     tr.cnt[(size_t)dy * tr.tw + dx] = spp;

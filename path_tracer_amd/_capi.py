@@ -52,6 +52,7 @@ PROTOTYPES = {
     "ir_pinhole_get_ray": (C.c_int, [c_float_p, c_float_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_uint32, c_float_p]),
     "ir_set_integrator": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "ir_set_sample_block": (C.c_int, [ctx_p, C.c_uint32]),
     "ir_set_partition": (C.c_int, [ctx_p, C.c_int, C.c_uint32, C.c_uint32]),
     "ir_render": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "ir_render_async": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
@@ -64,6 +65,7 @@ PROTOTYPES = {
     "ir_last_render_seconds": (C.c_double, [ctx_p]),
     "ir_last_kernel_ms": (C.c_double, [ctx_p, c_u32_p]),
     "ir_samples_accumulated": (C.c_uint32, [ctx_p]),
+    "ir_set_samples_accumulated": (C.c_int, [ctx_p, C.c_uint32]),
     "ir_device_radiance": (C.c_void_p, [ctx_p]),
     "ir_device_counts": (C.c_void_p, [ctx_p]),
     "ir_bind_accumulator": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -66,6 +66,8 @@ struct ir_context {
 
     // integrator (reference defaults, renderer.rs:38-41)
     uint32_t bounces = 5, rr_start = 2;
+    uint32_t sample_block = 128;
+    DeviceBuf d_partials;
     uint64_t seed = 0x0123456789ABCDEFull;
 
     // partition
@@ -307,7 +309,7 @@ void ir_destroy(ir_context* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_rays);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
-    release(ctx->d_stats);
+    release(ctx->d_stats); release(ctx->d_partials);
     release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -434,6 +436,14 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
     return IR_OK;
 }
 
+int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block) {
+    if (!ctx) return IR_EINVAL;
+    if (samples_per_block == 0 || samples_per_block > 4096)
+        return fail(ctx, IR_EINVAL, "ir_set_sample_block: %u not in [1, 4096]", samples_per_block);
+    ctx->sample_block = samples_per_block;
+    return IR_OK;
+}
+
 int ir_set_partition(ir_context* ctx, int mode, uint32_t rank, uint32_t world) {
     if (!ctx) return IR_EINVAL;
     if (mode != IR_PARTITION_NONE && mode != IR_PARTITION_TILES && mode != IR_PARTITION_SAMPLES)
@@ -509,8 +519,15 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     if (base + spp > 0xffffffffull) return fail(ctx, IR_ELIMIT, "ir_render: sample index overflow");
 
     // bound the work of one launch (pixels x spheres x samples) so that a launch stays well under a second
-    const double unit = (double)n * (double)(ctx->n_spheres < 8 ? 8 : ctx->n_spheres);
+    const double unit = (double)n * (double)(accel == pt::kAccelLbvh ? 64 : (ctx->n_spheres < 8 ? 8 : ctx->n_spheres));
     uint32_t chunk = (uint32_t)std::fmin(4096.0, std::fmax(1.0, 4.0e12 / unit));
+    // whole sample blocks per launch, so that the block structure does not depend on the chunking
+    const uint32_t sb = ctx->sample_block;
+    chunk = chunk < sb ? sb : chunk / sb * sb;
+    const uint32_t max_blocks = ((spp < chunk ? spp : chunk) + sb - 1) / sb;
+    if (max_blocks > 1) IR_TRY(ensure(ctx, ctx->d_partials, (size_t)max_blocks * n * sizeof(float4)));
+    a.sample_block = sb;
+    a.partials = (float4*)ctx->d_partials.p;
     IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     uint32_t done = 0;
     while (done < spp) {
@@ -641,6 +658,12 @@ double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches) {
 }
 
 uint32_t ir_samples_accumulated(const ir_context* ctx) { return ctx ? ctx->samples_done : 0; }
+
+int ir_set_samples_accumulated(ir_context* ctx, uint32_t samples) {
+    if (!ctx) return IR_EINVAL;
+    ctx->samples_done = samples;
+    return IR_OK;
+}
 
 void* ir_device_radiance(ir_context* ctx) { return ctx ? (void*)film_sum(ctx) : nullptr; }
 void* ir_device_counts(ir_context* ctx) { return ctx ? (void*)film_counts(ctx) : nullptr; }

@@ -33,6 +33,13 @@ struct RenderArgs {
     uint32_t seed_lo, seed_hi;
     uint32_t spp, sample_base;
 
+    // Samples [sample_base, sample_base + spp) of a launch are cut into blocks of sample_block samples; one workgroup
+    // sums one block of its 16x16 pixels from zero (in sample order), the block sums are merged in block order.
+    // partials: n_blocks x (w*h) float4 scratch (unused when the launch has a single block).
+    uint32_t sample_block;
+    uint32_t n_blocks, wgs_per_layer;  // filled in by launch_render
+    float4* partials;
+
     float4* sum;       // running radiance sum (rgb) + sample weight (a)
     uint32_t* counts;  // samples per pixel
 

@@ -24,10 +24,10 @@ __device__ __forceinline__ f3 sky_eval(const RenderArgs& a, f3 dir) {
 }
 
 // (x, y) of this lane: 1D grid over the 16x16 blocks of the owned 64x64 tiles; waves are 8x8 pixels.
-__device__ __forceinline__ bool lane_pixel(uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world, uint32_t w,
+__device__ __forceinline__ bool lane_pixel(uint32_t wg, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world, uint32_t w,
                                            uint32_t h, uint32_t& x, uint32_t& y) {
-    const uint32_t k = blockIdx.x / kBlocksPerTile;
-    const uint32_t sub = blockIdx.x % kBlocksPerTile;
+    const uint32_t k = wg / kBlocksPerTile;
+    const uint32_t sub = wg % kBlocksPerTile;
     const uint32_t tile = tile_rank + k * tile_world;
     const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -72,8 +72,10 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
 
+    // grid = sample blocks (slowest) x owned tiles x 16 workgroups per tile
+    const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
     uint32_t x, y;
-    if (!lane_pixel(a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
+    if (!lane_pixel(wg, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
     const uint32_t pixel = y * a.w + x;
 
     // per-lane work statistics (STATS only): traces, discriminant >= 0 tests, hits
@@ -89,8 +91,14 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
     } else {
         r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
     }
-    float4 acc = a.sum[pixel];
-    const uint32_t B = a.bounces, R = a.rr_start, spp = a.spp;
+    // this workgroup's sample block: like one reference render() call it sums its samples from zero in sample order
+    // (TileAccumulator, tile_buffer.rs:24-28); the block sums are then merged into the accumulator in block order
+    // (Accumulator::merge_tile, full_buffer.rs:107-125), by merge_kernel or, for a single block, right here
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t first = blk * a.sample_block;
+    const uint32_t spp = (a.spp - first < a.sample_block) ? a.spp - first : a.sample_block;
+    const uint32_t sample_base = a.sample_base + first;
+    const uint32_t B = a.bounces, R = a.rr_start;
     const bool fast = a.fast_materials != 0;
 
     if (B == 0) {
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
             const uint32_t pkey = pixel_key(a.seed_lo, pixel);
 
             uint32_t s = 0, b = 0;
-            uint32_t skey = sample_key(a.seed_hi, pkey, a.sample_base);
+            uint32_t skey = sample_key(a.seed_hi, pkey, sample_base);
             f3 pos = pos0, nrm = nrm0;
             int idx = idx0;
             f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
@@ -174,14 +182,20 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
                     pos = pos0; nrm = nrm0; idx = idx0;
                     contrib = mk3(1.0f, 1.0f, 1.0f);
                     light = mk3(0.0f, 0.0f, 0.0f);
-                    skey = sample_key(a.seed_hi, pkey, a.sample_base + s);
+                    skey = sample_key(a.seed_hi, pkey, sample_base + s);
                     if (STATS && s < spp) { n_traces++; n_disc += disc0; n_hits++; }
                 }
             }
         }
     }
-    a.sum[pixel] = acc;
-    a.counts[pixel] += spp;
+    if (a.partials) {
+        a.partials[(size_t)blk * ((size_t)a.w * a.h) + pixel] = acc;
+    } else {
+        float4 t = a.sum[pixel];
+        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+        a.sum[pixel] = t;
+        a.counts[pixel] += spp;
+    }
 
     if (STATS) {
         // algorithmic counts, as the reference would execute them (primary ray per sample)
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void primary_hits_kernel(const HitsArgs a) {
     if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
     uint32_t x, y;
     const uint32_t tiles_x = (a.w + kTile - 1) / kTile;
-    if (!lane_pixel(tiles_x, 0u, 1u, a.w, a.h, x, y)) return;
+    if (!lane_pixel(blockIdx.x, tiles_x, 0u, 1u, a.w, a.h, x, y)) return;
     const uint32_t pixel = y * a.w + x;
     Ray r0;
     if (a.rays) {
@@ -216,6 +230,22 @@ __global__ __launch_bounds__(256) void primary_hits_kernel(const HitsArgs a) {
     const HitRec h = trace_any<ACCEL, false>(a, s_sph, r0.o, r0.d, wc);
     a.out_idx[pixel] = h.idx;
     if (a.out_t) a.out_t[pixel] = (h.idx >= 0) ? h.t : -1.0f;  // ray_miss: hit_distance = -1 (integrator.rs:158-164)
+}
+
+// Accumulator::merge_tile (full_buffer.rs:107-125) for the sample blocks of one launch: framebuffer += block sum, in
+// block order; sample_counts += samples of the launch.
+__global__ __launch_bounds__(256) void merge_kernel(const RenderArgs a) {
+    uint32_t x, y;
+    if (!lane_pixel(blockIdx.x, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
+    const uint32_t pixel = y * a.w + x;
+    const size_t npix = (size_t)a.w * a.h;
+    float4 t = a.sum[pixel];
+    for (uint32_t b = 0; b < a.n_blocks; ++b) {
+        const float4 p = a.partials[(size_t)b * npix + pixel];
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+    }
+    a.sum[pixel] = t;
+    a.counts[pixel] += a.spp;
 }
 
 // Accumulator::get_argb_pixel (full_buffer.rs:49-65) + convert_to_argb (utils.rs:4-9)
@@ -262,10 +292,14 @@ static uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) {
     return rank < n_tiles ? (n_tiles - rank + world - 1) / world : 0;
 }
 
-hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream) {
-    const uint32_t owned = owned_tiles(a.n_tiles, a.tile_rank, a.tile_world);
-    if (owned == 0 || a.spp == 0) return hipSuccess;
-    const dim3 grid(owned * kBlocksPerTile), block(256);
+hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStream_t stream) {
+    const uint32_t owned = owned_tiles(a_in.n_tiles, a_in.tile_rank, a_in.tile_world);
+    if (owned == 0 || a_in.spp == 0) return hipSuccess;
+    RenderArgs a = a_in;
+    a.wgs_per_layer = owned * kBlocksPerTile;
+    a.n_blocks = (a.spp + a.sample_block - 1) / a.sample_block;
+    if (a.n_blocks == 1) a.partials = nullptr;  // single block: the kernel merges into the accumulator itself
+    const dim3 grid(a.wgs_per_layer * a.n_blocks), block(256);
     if (accel == kAccelLbvh) {
         if (stats) {
             hipLaunchKernelGGL((render_kernel<kAccelLbvh, true>), grid, block, 0, stream, a);
@@ -283,7 +317,13 @@ hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t
             hipLaunchKernelGGL((render_kernel<kAccelLinear, false>), grid, block, lds, stream, a);
         }
     }
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.n_blocks > 1) {
+        hipLaunchKernelGGL(merge_kernel, dim3(a.wgs_per_layer), block, 0, stream, a);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream) {

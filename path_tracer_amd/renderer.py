@@ -91,6 +91,10 @@ class RayTracer:
         if seed is not None:
             self.seed = int(seed)
 
+    def set_sample_block(self, samples_per_block):
+        """Samples per accumulation block of a multi-sample render call (ir_set_sample_block; default 128)."""
+        _capi.check(self._ctx, _capi.lib.ir_set_sample_block(self._ctx, int(samples_per_block)))
+
     def set_partition(self, mode, rank, world):
         _capi.check(self._ctx, _capi.lib.ir_set_partition(self._ctx, int(mode), int(rank), int(world)))
 
@@ -158,6 +162,9 @@ class RayTracer:
 
     def samples_accumulated(self):
         return int(_capi.lib.ir_samples_accumulated(self._ctx))
+
+    def set_samples_accumulated(self, samples):
+        _capi.check(self._ctx, _capi.lib.ir_set_samples_accumulated(self._ctx, int(samples)))
 
     def close(self):
         """Drop for RayTracer (renderer.rs:182-191)."""

@@ -42,6 +42,7 @@ lib.orc_trace.restype = C.c_int32
 lib.orc_sample_hemisphere.argtypes = [_f, C.c_float, C.c_float, C.c_int, _f]
 lib.orc_sky_lookup.argtypes = [_f, C.c_uint32, C.c_uint32, _f, C.c_int, _f]
 lib.orc_set_sky_filter.argtypes = [C.c_int]
+lib.orc_set_sample_block.argtypes = [C.c_uint32]
 lib.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.orc_rng_draw.restype = C.c_float
 lib.orc_rng_mix32.argtypes = [C.c_uint32]
@@ -182,6 +183,11 @@ def sky_lookup(box, d, math_mode=0):
 def set_sky_filter(f):
     """0 = nearest (the reference), 1 = bilinear (the build's extension); process-global."""
     lib.orc_set_sky_filter(int(f))
+
+
+def set_sample_block(n):
+    """Samples per accumulation block of a multi-sample render (process-global; the build's default is 128)."""
+    lib.orc_set_sample_block(int(n))
 
 
 def rng_draw(seed, pixel, sample, k):

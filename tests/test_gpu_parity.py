@@ -196,6 +196,31 @@ def test_accumulate_equals_successive_calls(pta, tracer, oracle):
     assert tracer.get_current_size() == [w + 1, h]
 
 
+@pytest.mark.parametrize("block,spp", [(64, 200), (16, 40), (1, 5), (4096, 70)])
+def test_sample_blocks_match_oracle(pta, tracer, oracle, block, spp):
+    """A multi-sample call = consecutive blocks, each summed from zero (the reference's TileAccumulator) and merged in
+    order (merge_tile); blocks run as independent workgroups on the GPU, the oracle restates the same sum."""
+    from path_tracer_amd import workloads as W
+    w, h = 100, 70
+    scene = W.scene_s1()
+    cam = W.default_camera(w, h)
+    _setup(pta, tracer, scene, cam, 8, 2)
+    tracer.set_sample_block(block)
+    oracle.set_sample_block(block)
+    try:
+        tracer.render(scene, w, h, False, spp=spp)
+        tracer.render(scene, w, h, True, spp=spp // 2 + 1)      # second call accumulates onto a non-zero frame
+        s, c = tracer.get_radiance()
+        oc = oracle.camera_from(cam, w, h)
+        os_, ocnt, _, _ = oracle.render(oc, scene, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1)
+        oracle.render(oc, scene, spp // 2 + 1, bounces=8, rr_start=2, seed=SEED, math_mode=1, sample_base=spp, sums=os_, counts=ocnt)
+    finally:
+        tracer.set_sample_block(128)
+        oracle.set_sample_block(128)
+    assert np.array_equal(c, ocnt) and (c == spp + spp // 2 + 1).all()
+    assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
+
+
 def test_resolve_argb_within_one_lsb(pta, tracer, oracle):
     from path_tracer_amd import workloads as W
     w, h = 160, 90
