@@ -350,56 +350,78 @@ struct LbvhView {
     uint32_t n_nodes;
 };
 
-template <bool STATS>
-PT_DEV HitRec trace_lbvh(const LbvhView& v, f3 o, f3 d, uint32_t& disc_pos, uint32_t& node_visits, uint32_t& leaf_tests) {
-    float best = kF32Max;
-    int idx = -1;
+// Traversal state of one ray.  A traversal is cursor_begin + cursor_step until done(): the integrator's LBVH kernel
+// interleaves steps of different lanes' rays with shading (see render_lbvh_kernel), trace_lbvh runs one to the end.
+struct LbvhCursor {
+    f3 o, d;
+    float a4, a2, ix, iy, iz;
+    float best;
+    int idx;
+    uint32_t node;
+};
+PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
+    c.o = o;
+    c.d = d;
     const float a = dot(d, d);
-    const float a4 = 4.0f * a;
-    const float a2 = 2.0f * a;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;  // +-inf for an axis-parallel ray
-    uint32_t node = 0;
-    while (node < v.n_nodes) {
-        const float4 n0 = v.nodes[2 * node];
-        const float4 n1 = v.nodes[2 * node + 1];
-        if (STATS) node_visits++;
-        const float lx = n0.x - o.x, ly = n0.y - o.y, lz = n0.z - o.z;
-        const float hx = n1.x - o.x, hy = n1.y - o.y, hz = n1.z - o.z;
-        const float pad = (__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)) + __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy)) +
-                           __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * 0.0078125f;
-        const float t1x = (lx - pad) * ix, t2x = (hx + pad) * ix;
-        const float t1y = (ly - pad) * iy, t2y = (hy + pad) * iy;
-        const float t1z = (lz - pad) * iz, t2z = (hz + pad) * iz;
-        // fmin/fmax return the non-NaN operand: a 0*inf slab (origin on the padded plane, d == 0) is unconstrained
-        const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
-        const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
-        const bool hit = (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= best);
-        const int skip = __builtin_bit_cast(int, n0.w), leaf = __builtin_bit_cast(int, n1.w);
-        if (hit && leaf >= 0) {
-            const uint32_t first = (uint32_t)leaf >> 3, count = (uint32_t)leaf & 7u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4 s = v.leaf_spheres[first + k];
-                if (STATS) leaf_tests++;
-                f3 oc = o - mk3(s.x, s.y, s.z);
-                float b = 2.0f * dot(d, oc);
-                float c = dot(oc, oc) - s.w;
-                float disc = b * b - a4 * c;
-                if (disc < 0.0f) continue;
-                if (STATS) disc_pos++;
-                float sq = sqrt_cr(disc);
-                float t = (-b - sq) / a2;
-                const int orig = v.leaf_index[first + k];
-                if (t > 0.0f && (t < best || (t == best && orig < idx))) {
-                    idx = orig;
-                    best = t;
-                }
+    c.a4 = 4.0f * a;
+    c.a2 = 2.0f * a;
+    c.ix = 1.0f / d.x;  // +-inf for an axis-parallel ray
+    c.iy = 1.0f / d.y;
+    c.iz = 1.0f / d.z;
+    c.best = kF32Max;
+    c.idx = -1;
+    c.node = 0;
+}
+// visit one node (and, for a leaf whose box is hit, its <= kLeafMax spheres)
+template <bool STATS>
+PT_DEV void cursor_step(const LbvhView& v, LbvhCursor& c, uint32_t& disc_pos, uint32_t& node_visits, uint32_t& leaf_tests) {
+    const f3 o = c.o, d = c.d;
+    const float4 n0 = v.nodes[2 * c.node];
+    const float4 n1 = v.nodes[2 * c.node + 1];
+    if (STATS) node_visits++;
+    const float lx = n0.x - o.x, ly = n0.y - o.y, lz = n0.z - o.z;
+    const float hx = n1.x - o.x, hy = n1.y - o.y, hz = n1.z - o.z;
+    const float pad = (__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)) + __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy)) +
+                       __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * 0.0078125f;
+    const float t1x = (lx - pad) * c.ix, t2x = (hx + pad) * c.ix;
+    const float t1y = (ly - pad) * c.iy, t2y = (hy + pad) * c.iy;
+    const float t1z = (lz - pad) * c.iz, t2z = (hz + pad) * c.iz;
+    // fmin/fmax return the non-NaN operand: a 0*inf slab (origin on the padded plane, d == 0) is unconstrained
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+    const bool hit = (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= c.best);
+    const int skip = __builtin_bit_cast(int, n0.w), leaf = __builtin_bit_cast(int, n1.w);
+    if (hit && leaf >= 0) {
+        const uint32_t first = (uint32_t)leaf >> 3, count = (uint32_t)leaf & 7u;
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 s = v.leaf_spheres[first + k];
+            if (STATS) leaf_tests++;
+            f3 oc = o - mk3(s.x, s.y, s.z);
+            float b = 2.0f * dot(d, oc);
+            float cc = dot(oc, oc) - s.w;
+            float disc = b * b - c.a4 * cc;
+            if (disc < 0.0f) continue;
+            if (STATS) disc_pos++;
+            float sq = sqrt_cr(disc);
+            float t = (-b - sq) / c.a2;
+            const int orig = v.leaf_index[first + k];
+            if (t > 0.0f && (t < c.best || (t == c.best && orig < c.idx))) {
+                c.idx = orig;
+                c.best = t;
             }
         }
-        node = (hit && leaf < 0) ? node + 1 : (uint32_t)skip;
     }
+    c.node = (hit && leaf < 0) ? c.node + 1 : (uint32_t)skip;
+}
+
+template <bool STATS>
+PT_DEV HitRec trace_lbvh(const LbvhView& v, f3 o, f3 d, uint32_t& disc_pos, uint32_t& node_visits, uint32_t& leaf_tests) {
+    LbvhCursor c;
+    cursor_begin(c, o, d);
+    while (c.node < v.n_nodes) cursor_step<STATS>(v, c, disc_pos, node_visits, leaf_tests);
     HitRec h;
-    h.t = best;
-    h.idx = idx;
+    h.t = c.best;
+    h.idx = c.idx;
     return h;
 }
 

@@ -210,6 +210,166 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// LBVH integrator: same samples, same sums as render_kernel, different schedule.  With a tree, the length of a
+// traversal varies wildly between the rays of one wave (measured on the 10k-sphere scene: 10 % of the lanes active
+// when every lane waits for the slowest ray of each bounce).  Here a lane is either TRAVERSING (it advances its own
+// ray by one node per step) or WAITING for the shading block (finish the previous ray: hit point or sky + sample
+// accumulation + regeneration; then emission, bounce sampling, roulette and the next ray).  The wave runs traversal
+// steps for whoever is traversing and runs the shading block only once enough lanes wait for it (or nobody is left
+// traversing), so short rays do not sit out long ones: they go on to their next ray.  Every lane still runs its own
+// pixel's samples in order, so per-pixel sums are unchanged.
+// ----------------------------------------------------------------------------------------------------
+constexpr uint32_t kShadeBatch = 24;   // run the shading block when this many lanes wait for it
+constexpr uint32_t kStepsPerRound = 4; // traversal steps between two looks at the wave's state
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_lbvh_kernel(const RenderArgs a) {
+    const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
+    uint32_t x, y;
+    if (!lane_pixel(wg, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
+    const uint32_t pixel = y * a.w + x;
+    uint32_t n_traces = 0, n_disc = 0, n_hits = 0;
+    WorkCounters wc0 = {0, 0, 0}, wc = {0, 0, 0};
+
+    Ray r0;
+    if (a.rays) {
+        const float* p = a.rays + 6 * (size_t)pixel;
+        r0.o = mk3(p[0], p[1], p[2]);
+        r0.d = mk3(p[3], p[4], p[5]);
+    } else {
+        r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
+    }
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t first = blk * a.sample_block;
+    const uint32_t spp = (a.spp - first < a.sample_block) ? a.spp - first : a.sample_block;
+    const uint32_t sample_base = a.sample_base + first;
+    const uint32_t B = a.bounces, R = a.rr_start;
+    const bool fast = a.fast_materials != 0;
+
+    uint32_t s = 0;  // samples finished by this lane; the lane has work while s < spp
+    f3 pos0 = mk3(0, 0, 0), nrm0 = mk3(0, 0, 0);
+    int idx0 = -1;
+    uint32_t disc0 = 0;
+    if (B == 0) {
+        for (; s < spp; ++s) { acc.x += 0.0f; acc.y += 0.0f; acc.z += 0.0f; acc.w += 1.0f; }
+    } else {
+        const HitRec h0 = trace_lbvh<STATS>(a.bvh, r0.o, r0.d, wc0.disc, wc0.nodes, wc0.leaves);
+        disc0 = wc0.disc;
+        if (h0.idx < 0) {
+            f3 light = mk3(0.0f, 0.0f, 0.0f) + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
+            for (; s < spp; ++s) { acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f; }
+            if (STATS) { n_traces = spp; n_disc = disc0 * spp; }
+        } else {
+            hit_geometry(a.spheres[h0.idx], r0.o, r0.d, h0.t, pos0, nrm0);
+            idx0 = h0.idx;
+            if (STATS) { n_traces = 1; n_disc = disc0; n_hits = 1; }
+        }
+    }
+    const uint32_t pkey = pixel_key(a.seed_lo, pixel);
+    uint32_t b = 0;
+    uint32_t skey = sample_key(a.seed_hi, pkey, sample_base);
+    f3 pos = pos0, nrm = nrm0;
+    int idx = idx0;
+    f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
+    LbvhCursor cur;
+    cursor_begin(cur, mk3(0, 0, 0), mk3(0, 0, 1));
+    cur.node = a.bvh.n_nodes;
+    bool traversing = false;  // cur holds an unfinished traversal
+    bool landed = false;      // cur holds a finished traversal whose result has not been consumed yet
+
+    for (;;) {
+        const bool waiting = !traversing && s < spp;
+        const uint32_t n_wait = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(waiting));
+        const uint32_t n_trav = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(traversing));
+        if (n_wait == 0 && n_trav == 0) break;
+        if (n_wait >= kShadeBatch || n_trav == 0) {
+            if (waiting) {
+                if (landed) {  // consume the finished traversal (integrator.rs:50-51, 82-90)
+                    landed = false;
+                    if (STATS) { n_traces++; }
+                    if (cur.idx >= 0) {
+                        if (STATS) n_hits++;
+                        hit_geometry(a.spheres[cur.idx], cur.o, cur.d, cur.best, pos, nrm);
+                        idx = cur.idx;
+                    } else {
+                        light = light + sky_eval(a, cur.d) * contrib;
+                        idx = -1;  // sample finished
+                    }
+                }
+                for (;;) {
+                    if (idx < 0) {  // finish the sample, regenerate at the primary hit
+                        acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
+                        ++s;
+                        if (s >= spp) break;
+                        b = 0;
+                        pos = pos0; nrm = nrm0; idx = idx0;
+                        contrib = mk3(1.0f, 1.0f, 1.0f);
+                        light = mk3(0.0f, 0.0f, 0.0f);
+                        skey = sample_key(a.seed_hi, pkey, sample_base + s);
+                        if (STATS) { n_traces++; n_disc += disc0; n_hits++; }
+                    }
+                    // shade the hit of bounce b (integrator.rs:50-81)
+                    const float4 m_brdf = a.shade[2 * idx];
+                    const float4 m_emit = a.shade[2 * idx + 1];
+                    light = light + mk3(m_emit.x, m_emit.y, m_emit.z) * contrib;
+                    const float r1 = draw(skey, 3 * b);
+                    const float r2 = draw(skey, 3 * b + 1);
+                    const f3 wi = sample_hemisphere(nrm, r1, r2);
+                    const float cos_theta = __builtin_fmaxf(dot(wi, nrm), 0.0f);
+                    contrib = contrib * scatter_weight(mk3(m_brdf.x, m_brdf.y, m_brdf.z), cos_theta, fast);
+                    bool done = false;
+                    if (b >= R) {
+                        const float p = __builtin_fmaxf(contrib.x, __builtin_fmaxf(contrib.y, contrib.z));
+                        if (draw(skey, 3 * b + 2) > p) {
+                            done = true;
+                        } else {
+                            contrib = roulette_divide(contrib, p, fast);
+                        }
+                    }
+                    if (!done) {
+                        ++b;
+                        if (b < B) {
+                            cursor_begin(cur, pos + nrm * kEps, wi);
+                            traversing = true;
+                            break;
+                        }
+                    }
+                    idx = -1;  // roulette or bounce budget ended the path: no sky term (integrator.rs:47,74,92)
+                }
+            }
+        }
+        for (uint32_t k = 0; k < kStepsPerRound; ++k) {
+            if (traversing) {
+                cursor_step<STATS>(a.bvh, cur, wc.disc, wc.nodes, wc.leaves);
+                if (cur.node >= a.bvh.n_nodes) {
+                    traversing = false;
+                    landed = true;
+                }
+            }
+        }
+    }
+    if (STATS) n_disc += wc.disc;
+
+    if (a.partials) {
+        a.partials[(size_t)blk * ((size_t)a.w * a.h) + pixel] = acc;
+    } else {
+        float4 t = a.sum[pixel];
+        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+        a.sum[pixel] = t;
+        a.counts[pixel] += spp;
+    }
+    if (STATS) {
+        atomicAdd(&a.stats[0], (unsigned long long)spp);
+        atomicAdd(&a.stats[1], (unsigned long long)n_traces);
+        atomicAdd(&a.stats[2], (unsigned long long)n_traces * a.n_spheres);
+        atomicAdd(&a.stats[3], (unsigned long long)n_disc);
+        atomicAdd(&a.stats[4], (unsigned long long)n_hits);
+        atomicAdd(&a.stats[5], (unsigned long long)wc.nodes + wc0.nodes);
+        atomicAdd(&a.stats[6], (unsigned long long)wc.leaves + wc0.leaves);
+    }
+}
+
 template <int ACCEL>
 __global__ __launch_bounds__(256) void primary_hits_kernel(const HitsArgs a) {
     extern __shared__ float4 s_sph[];
@@ -302,9 +462,9 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     const dim3 grid(a.wgs_per_layer * a.n_blocks), block(256);
     if (accel == kAccelLbvh) {
         if (stats) {
-            hipLaunchKernelGGL((render_kernel<kAccelLbvh, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((render_lbvh_kernel<true>), grid, block, 0, stream, a);
         } else {
-            hipLaunchKernelGGL((render_kernel<kAccelLbvh, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((render_lbvh_kernel<false>), grid, block, 0, stream, a);
         }
     } else {
         size_t lds = (size_t)a.n_spheres * sizeof(float4);

@@ -25,6 +25,7 @@ extern "C" {
     pub fn ir_set_skybox(ctx: *mut ir_context, rgb: *const c_float, w: u32, h: u32) -> c_int;
     pub fn ir_set_sky_filter(ctx: *mut ir_context, filter: c_int) -> c_int;
     pub fn ir_set_accel(ctx: *mut ir_context, accel: c_int) -> c_int;
+    pub fn ir_get_accel_info(ctx: *mut ir_context, out_accel: *mut c_int, out_nodes: *mut u32, out_depth: *mut u32) -> c_int;
     pub fn ir_set_pinhole(ctx: *mut ir_context, local_to_world: *const c_float, position: *const c_float, fov: c_float, aspect_ratio: c_float) -> c_int;
     pub fn ir_set_primary_rays(ctx: *mut ir_context, rays: *const c_float, w: u32, h: u32) -> c_int;
     pub fn ir_pinhole_compute(position: *const c_float, rotation_xyz: *const c_float, focal_length: c_float, sensor_size: c_float,
@@ -33,6 +34,7 @@ extern "C" {
     pub fn ir_pinhole_get_ray(local_to_world: *const c_float, position: *const c_float, fov: c_float, aspect_ratio: c_float,
                               width: u32, height: u32, x: u32, y: u32, out6: *mut c_float) -> c_int;
     pub fn ir_set_integrator(ctx: *mut ir_context, bounces: u32, max_compulsory_bounces: u32, seed: u64) -> c_int;
+    pub fn ir_set_sample_block(ctx: *mut ir_context, samples_per_block: u32) -> c_int;
     pub fn ir_set_partition(ctx: *mut ir_context, mode: c_int, rank: u32, world: u32) -> c_int;
     pub fn ir_render(ctx: *mut ir_context, width: u32, height: u32, spp: u32, accumulate: c_int) -> c_int;
     pub fn ir_render_async(ctx: *mut ir_context, width: u32, height: u32, spp: u32, accumulate: c_int) -> c_int;
@@ -45,11 +47,14 @@ extern "C" {
     pub fn ir_last_render_seconds(ctx: *const ir_context) -> c_double;
     pub fn ir_last_kernel_ms(ctx: *const ir_context, n_launches: *mut u32) -> c_double;
     pub fn ir_samples_accumulated(ctx: *const ir_context) -> u32;
+    pub fn ir_set_samples_accumulated(ctx: *mut ir_context, samples: u32) -> c_int;
     pub fn ir_device_radiance(ctx: *mut ir_context) -> *mut c_void;
     pub fn ir_device_counts(ctx: *mut ir_context) -> *mut c_void;
     pub fn ir_bind_accumulator(ctx: *mut ir_context, d_sum_rgba: *mut c_void, d_counts: *mut c_void, width: u32, height: u32) -> c_int;
     pub fn ir_enable_stats(ctx: *mut ir_context, enable: c_int) -> c_int;
     pub fn ir_get_stats(ctx: *mut ir_context, out5: *mut u64) -> c_int;
+    pub fn ir_get_accel_stats(ctx: *mut ir_context, out2: *mut u64) -> c_int;
+    pub fn ir_selftest_exact_math(ctx: *mut ir_context, out_mismatches: *mut u64, n_out: u32, log2_random_samples: u32) -> c_int;
     pub fn ir_exr_load(path: *const c_char, out_rgb: *mut *mut c_float, out_w: *mut u32, out_h: *mut u32) -> c_int;
     pub fn ir_exr_last_error() -> *const c_char;
     pub fn ir_exr_save(path: *const c_char, rgb: *const c_float, w: u32, h: u32, compression: c_int, pixel_type: c_int) -> c_int;
