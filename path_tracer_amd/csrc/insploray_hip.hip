@@ -48,7 +48,7 @@ struct ir_context {
     DeviceBuf d_spheres, d_shade;
     // LBVH (built on the host at ir_set_spheres / ir_set_accel when the LBVH is the selected structure)
     DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index;
-    uint32_t bvh_nodes = 0, bvh_depth = 0;
+    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_stack = 0;
     bool bvh_valid = false;
     float sky[3] = {0.0f, 0.0f, 0.0f};
     DeviceBuf d_skybox;
@@ -211,20 +211,21 @@ int ensure_bvh(ir_context* ctx) {
     if (selected_accel(ctx) != pt::kAccelLbvh || ctx->bvh_valid) return IR_OK;
     pt::Lbvh t;
     pt::build_lbvh(ctx->h_spheres.data(), ctx->n_spheres, t);
-    IR_TRY(upload(ctx, ctx->d_bvh_nodes, t.nodes.data(), t.nodes.size() * sizeof(pt::BvhNode)));
+    IR_TRY(upload(ctx, ctx->d_bvh_nodes, t.wide.data(), t.wide.size() * sizeof(pt::WideNode)));
     IR_TRY(upload(ctx, ctx->d_bvh_spheres, t.leaf_spheres.data(), t.leaf_spheres.size() * sizeof(float)));
     IR_TRY(upload(ctx, ctx->d_bvh_index, t.leaf_index.data(), t.leaf_index.size() * sizeof(int32_t)));
-    ctx->bvh_nodes = (uint32_t)t.nodes.size();
+    ctx->bvh_nodes = (uint32_t)t.wide.size();
     ctx->bvh_depth = t.max_depth;
+    ctx->bvh_stack = t.stack_depth;
     ctx->bvh_valid = true;
     return IR_OK;
 }
 
 void fill_bvh(const ir_context* ctx, pt::LbvhView& v) {
-    v.nodes = (const float4*)ctx->d_bvh_nodes.p;
+    v.wide = (const float4*)ctx->d_bvh_nodes.p;
     v.leaf_spheres = (const float4*)ctx->d_bvh_spheres.p;
     v.leaf_index = (const int*)ctx->d_bvh_index.p;
-    v.n_nodes = ctx->bvh_nodes;
+    v.stack_depth = ctx->bvh_stack;
 }
 
 void fill_camera(const ir_context* ctx, pt::CameraBlock& c) {

@@ -21,6 +21,7 @@ uint32_t expand10(uint32_t v) {
 }
 
 struct Builder {
+    bool balanced = false;  // median splits only (depth <= log2(n) + 1): fallback when the Morton tree is too deep
     const float* s;
     std::vector<uint32_t> code;
     std::vector<uint32_t> order;
@@ -64,7 +65,7 @@ struct Builder {
             uint32_t split = first + count / 2;
             int b = bit;
             const uint32_t diff = code[order[first]] ^ code[order[last - 1]];
-            if (diff != 0) {
+            if (diff != 0 && !balanced) {
                 while (b >= 0 && !((diff >> b) & 1u)) --b;
                 // first element whose bit b is set (codes are sorted)
                 uint32_t lo_i = first, hi_i = last - 1;
@@ -86,13 +87,13 @@ struct Builder {
 
 }  // namespace
 
-void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
+static void build_preorder(const float* spheres_xyzr, uint32_t n, Lbvh& out, bool balanced) {
     out.nodes.clear();
     out.leaf_spheres.clear();
     out.leaf_index.clear();
     out.max_depth = 0;
-    if (n == 0) return;
     Builder b;
+    b.balanced = balanced;
     b.s = spheres_xyzr;
     b.out = &out;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -121,7 +122,7 @@ void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
     std::sort(b.order.begin(), b.order.end(), [&](uint32_t x, uint32_t y) {
         return b.code[x] != b.code[y] ? b.code[x] < b.code[y] : x < y;
     });
-    out.nodes.reserve(2 * (size_t)n / 2 + 8);
+    out.nodes.reserve((size_t)n + 8);
     b.build(0, n, 29, 0);
     out.leaf_spheres.resize((size_t)n * 4);
     out.leaf_index.resize(n);
@@ -134,6 +135,50 @@ void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
         o[3] = p[3] * p[3];  // radius * radius (integrator.rs:111)
         out.leaf_index[i] = (int32_t)b.order[i];
     }
+}
+
+void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
+    out.wide.clear();
+    out.stack_depth = 0;
+    out.nodes.clear();
+    out.leaf_spheres.clear();
+    out.leaf_index.clear();
+    out.max_depth = 0;
+    if (n == 0) return;
+    build_preorder(spheres_xyzr, n, out, false);
+    if (out.max_depth + 1 > kMaxStack) build_preorder(spheres_xyzr, n, out, true);  // depth <= log2(n) + 1 <= 25
+
+    // wide layout: inner nodes renumbered in pre-order; children of pre-order node i are i + 1 and nodes[i + 1].skip
+    const size_t m = out.nodes.size();
+    std::vector<int32_t> ref(m);
+    int32_t n_inner = 0;
+    for (size_t i = 0; i < m; ++i) ref[i] = out.nodes[i].leaf < 0 ? n_inner++ : -(out.nodes[i].leaf + 1);
+    auto put = [](WideNode& w, int row, const float* xyz, int32_t word) {
+        w.v[4 * row + 0] = xyz[0];
+        w.v[4 * row + 1] = xyz[1];
+        w.v[4 * row + 2] = xyz[2];
+        memcpy(&w.v[4 * row + 3], &word, 4);
+    };
+    if (out.nodes[0].leaf >= 0) {  // the whole tree is one leaf: root with that leaf on the left, an empty leaf on the right
+        WideNode w;
+        put(w, 0, out.nodes[0].lo, ref[0]);
+        put(w, 1, out.nodes[0].hi, -1);  // first 0, count 0
+        put(w, 2, out.nodes[0].lo, 0);
+        put(w, 3, out.nodes[0].hi, 0);
+        out.wide.push_back(w);
+    } else {
+        out.wide.resize((size_t)n_inner);
+        for (size_t i = 0; i < m; ++i) {
+            if (out.nodes[i].leaf >= 0) continue;
+            const size_t l = i + 1, r = (size_t)out.nodes[l].skip;
+            WideNode& w = out.wide[(size_t)ref[i]];
+            put(w, 0, out.nodes[l].lo, ref[l]);
+            put(w, 1, out.nodes[l].hi, ref[r]);
+            put(w, 2, out.nodes[r].lo, 0);
+            put(w, 3, out.nodes[r].hi, 0);
+        }
+    }
+    out.stack_depth = out.max_depth + 1;
 }
 
 }  // namespace pt

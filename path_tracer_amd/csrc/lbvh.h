@@ -24,7 +24,20 @@ struct BvhNode {
     int32_t leaf;
 };
 
+// Traversal layout ("wide" inner nodes: both children's boxes in the parent, 64 bytes), built from the pre-order tree:
+//   [0] = (left.lo.xyz,  left ref)   [1] = (left.hi.xyz,  right ref)   [2] = (right.lo.xyz, 0)   [3] = (right.hi.xyz, 0)
+// ref >= 0: index of an inner node; ref < 0: leaf, -(ref + 1) = first * 8 + count into the leaf-ordered arrays
+// (count may be 0: the padding child of a tree that is a single leaf).  Node 0 is the root.  One fetch tests both
+// children, the nearer one is entered first and the farther one is pushed on a per-lane stack of at most
+// `stack_depth` entries (<= kMaxStack, enforced by the builder).
+struct WideNode {
+    float v[16];
+};
+constexpr uint32_t kMaxStack = 32;
+
 struct Lbvh {
+    std::vector<WideNode> wide;
+    uint32_t stack_depth = 0;
     std::vector<BvhNode> nodes;
     std::vector<float> leaf_spheres;   // 4 floats per sphere in leaf order: cx, cy, cz, r*r
     std::vector<int32_t> leaf_index;   // original sphere index per leaf-order slot

@@ -335,29 +335,34 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
 }
 
 // ----------------------------------------------------------------------------------------------------
-// Closest hit through the LBVH (lbvh.h).  Stackless pre-order traversal with skip links.  Leaf tests are the scan's
-// arithmetic; the accept rule adds "equal t keeps the lower original index", which is what a scan in index order with
-// a strict '<' returns.  Node tests are conservative: each box is inflated by pad = (L1 distance from the ray origin
+// Closest hit through the LBVH (lbvh.h).  Ordered traversal: an inner node carries both children's boxes, the nearer
+// hit child is entered first and the farther one is pushed on a small per-lane stack, so that `best` shrinks early
+// and prunes the far field.  Leaf tests are the scan's arithmetic; the accept rule adds "equal t keeps the lower
+// original index", which is what a scan in index order with a strict '<' returns, so the result does not depend on
+// the visiting order.  Node tests are conservative: each box is inflated by pad = (L1 distance from the ray origin
 // to the farthest box corner) * 2^-7 before the slab test.  That pad dominates (a) the band in which the rounded
 // discriminant of a geometrically missed sphere can still come out >= 0 (sqrt(K*eps)*|oc|, K ~ 64 => 2e-3 |oc|) and
 // (b) the error of the computed root against the geometric entry distance, so no sphere the scan would accept with
 // t <= best is ever pruned.
 // ----------------------------------------------------------------------------------------------------
 struct LbvhView {
-    const float4* __restrict__ nodes;         // 2 x float4 per node: (lo.xyz, skip), (hi.xyz, leaf)
+    const float4* __restrict__ wide;          // 4 x float4 per inner node (lbvh.h WideNode)
     const float4* __restrict__ leaf_spheres;  // leaf order: (cx, cy, cz, r*r)
     const int* __restrict__ leaf_index;       // leaf order -> original sphere index
-    uint32_t n_nodes;
+    uint32_t stack_depth;                     // entries a traversal may need (<= kMaxStack)
 };
 
-// Traversal state of one ray.  A traversal is cursor_begin + cursor_step until done(): the integrator's LBVH kernel
-// interleaves steps of different lanes' rays with shading (see render_lbvh_kernel), trace_lbvh runs one to the end.
+// Traversal state of one ray.  A traversal is cursor_begin + cursor_step until cur == kCursorDone: the integrator's
+// LBVH kernel interleaves steps of different lanes' rays with shading (render_lbvh_kernel), trace_lbvh runs one to
+// the end.  The stack lives outside (LDS on the device: entry k of this lane at stack[k * stride]).
+constexpr int kCursorDone = 0x7fffffff;
 struct LbvhCursor {
     f3 o, d;
     float a4, a2, ix, iy, iz;
     float best;
     int idx;
-    uint32_t node;
+    int cur;       // >= 0: inner node, < 0: leaf -(first * 8 + count) - 1, kCursorDone: finished
+    uint32_t sp;   // stack entries in use
 };
 PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
     c.o = o;
@@ -370,29 +375,55 @@ PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
     c.iz = 1.0f / d.z;
     c.best = kF32Max;
     c.idx = -1;
-    c.node = 0;
+    c.cur = 0;
+    c.sp = 0;
 }
-// visit one node (and, for a leaf whose box is hit, its <= kLeafMax spheres)
-template <bool STATS>
-PT_DEV void cursor_step(const LbvhView& v, LbvhCursor& c, uint32_t& disc_pos, uint32_t& node_visits, uint32_t& leaf_tests) {
-    const f3 o = c.o, d = c.d;
-    const float4 n0 = v.nodes[2 * c.node];
-    const float4 n1 = v.nodes[2 * c.node + 1];
-    if (STATS) node_visits++;
-    const float lx = n0.x - o.x, ly = n0.y - o.y, lz = n0.z - o.z;
-    const float hx = n1.x - o.x, hy = n1.y - o.y, hz = n1.z - o.z;
+PT_DEV bool padded_box_hit(const LbvhCursor& c, float4 lo, float4 hi, float& tmin) {
+    const float lx = lo.x - c.o.x, ly = lo.y - c.o.y, lz = lo.z - c.o.z;
+    const float hx = hi.x - c.o.x, hy = hi.y - c.o.y, hz = hi.z - c.o.z;
     const float pad = (__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)) + __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy)) +
                        __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * 0.0078125f;
     const float t1x = (lx - pad) * c.ix, t2x = (hx + pad) * c.ix;
     const float t1y = (ly - pad) * c.iy, t2y = (hy + pad) * c.iy;
     const float t1z = (lz - pad) * c.iz, t2z = (hz + pad) * c.iz;
     // fmin/fmax return the non-NaN operand: a 0*inf slab (origin on the padded plane, d == 0) is unconstrained
-    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
     const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
-    const bool hit = (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= c.best);
-    const int skip = __builtin_bit_cast(int, n0.w), leaf = __builtin_bit_cast(int, n1.w);
-    if (hit && leaf >= 0) {
-        const uint32_t first = (uint32_t)leaf >> 3, count = (uint32_t)leaf & 7u;
+    return (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= c.best);
+}
+// one step: visit the current inner node (test both children, enter the nearer, push the farther) and, if that
+// leads to a leaf, test its <= kLeafMax spheres and pop.  Precondition: c.cur != kCursorDone.
+template <bool STATS>
+PT_DEV void cursor_step(const LbvhView& v, LbvhCursor& c, int* stack, uint32_t stride, uint32_t& disc_pos, uint32_t& node_visits,
+                        uint32_t& leaf_tests) {
+    int cur = c.cur;
+    if (cur >= 0) {
+        const float4 n0 = v.wide[4 * (size_t)cur], n1 = v.wide[4 * (size_t)cur + 1];
+        const float4 n2 = v.wide[4 * (size_t)cur + 2], n3 = v.wide[4 * (size_t)cur + 3];
+        if (STATS) node_visits += 2;  // two box tests
+        float tl, tr;
+        const bool hl = padded_box_hit(c, n0, n1, tl), hr = padded_box_hit(c, n2, n3, tr);
+        const int rl = __builtin_bit_cast(int, n0.w), rr = __builtin_bit_cast(int, n1.w);
+        if (hl && hr) {
+            const bool right_first = tr < tl;
+            stack[c.sp * stride] = right_first ? rl : rr;
+            c.sp++;
+            cur = right_first ? rr : rl;
+        } else if (hl) {
+            cur = rl;
+        } else if (hr) {
+            cur = rr;
+        } else if (c.sp > 0) {
+            c.sp--;
+            cur = stack[c.sp * stride];
+        } else {
+            cur = kCursorDone;
+        }
+    }
+    if (cur < 0) {
+        const uint32_t leaf = (uint32_t)(-(cur + 1));
+        const uint32_t first = leaf >> 3, count = leaf & 7u;
+        const f3 o = c.o, d = c.d;
         for (uint32_t k = 0; k < count; ++k) {
             const float4 s = v.leaf_spheres[first + k];
             if (STATS) leaf_tests++;
@@ -410,15 +441,22 @@ PT_DEV void cursor_step(const LbvhView& v, LbvhCursor& c, uint32_t& disc_pos, ui
                 c.best = t;
             }
         }
+        if (c.sp > 0) {
+            c.sp--;
+            cur = stack[c.sp * stride];
+        } else {
+            cur = kCursorDone;
+        }
     }
-    c.node = (hit && leaf < 0) ? c.node + 1 : (uint32_t)skip;
+    c.cur = cur;
 }
 
 template <bool STATS>
-PT_DEV HitRec trace_lbvh(const LbvhView& v, f3 o, f3 d, uint32_t& disc_pos, uint32_t& node_visits, uint32_t& leaf_tests) {
+PT_DEV HitRec trace_lbvh(const LbvhView& v, int* stack, uint32_t stride, f3 o, f3 d, uint32_t& disc_pos, uint32_t& node_visits,
+                         uint32_t& leaf_tests) {
     LbvhCursor c;
     cursor_begin(c, o, d);
-    while (c.node < v.n_nodes) cursor_step<STATS>(v, c, disc_pos, node_visits, leaf_tests);
+    while (c.cur != kCursorDone) cursor_step<STATS>(v, c, stack, stride, disc_pos, node_visits, leaf_tests);
     HitRec h;
     h.t = c.best;
     h.idx = c.idx;

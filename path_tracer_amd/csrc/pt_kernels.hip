@@ -49,11 +49,13 @@ struct WorkCounters {
     uint32_t disc, nodes, leaves;
 };
 
-// closest hit by the selected structure; centre of sphere idx for closest_hit
+// closest hit by the selected structure; centre of sphere idx for closest_hit.  (The LBVH has its own integrator
+// kernel below; only the primary-hits kernel reaches the tree through here.)
 template <int ACCEL, bool STATS, class Args>
 __device__ __forceinline__ HitRec trace_any(const Args& a, const float4* s_sph, f3 o, f3 d, WorkCounters& wc) {
     if constexpr (ACCEL == kAccelLbvh) {
-        return trace_lbvh<STATS>(a.bvh, o, d, wc.disc, wc.nodes, wc.leaves);
+        int* stack = reinterpret_cast<int*>(const_cast<float4*>(s_sph)) + threadIdx.x;  // dynamic LDS = the stacks
+        return trace_lbvh<STATS>(a.bvh, stack, blockDim.x, o, d, wc.disc, wc.nodes, wc.leaves);
     } else {
         return trace_linear<STATS>(s_sph, a.n_spheres, o, d, wc.disc);
     }
@@ -225,6 +227,8 @@ constexpr uint32_t kStepsPerRound = 4; // traversal steps between two looks at t
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void render_lbvh_kernel(const RenderArgs a) {
+    extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
+    int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
     const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
     uint32_t x, y;
     if (!lane_pixel(wg, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void render_lbvh_kernel(const RenderArgs a) {
     if (B == 0) {
         for (; s < spp; ++s) { acc.x += 0.0f; acc.y += 0.0f; acc.z += 0.0f; acc.w += 1.0f; }
     } else {
-        const HitRec h0 = trace_lbvh<STATS>(a.bvh, r0.o, r0.d, wc0.disc, wc0.nodes, wc0.leaves);
+        const HitRec h0 = trace_lbvh<STATS>(a.bvh, stack, 256u, r0.o, r0.d, wc0.disc, wc0.nodes, wc0.leaves);
         disc0 = wc0.disc;
         if (h0.idx < 0) {
             f3 light = mk3(0.0f, 0.0f, 0.0f) + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void render_lbvh_kernel(const RenderArgs a) {
     f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
     LbvhCursor cur;
     cursor_begin(cur, mk3(0, 0, 0), mk3(0, 0, 1));
-    cur.node = a.bvh.n_nodes;
+    cur.cur = kCursorDone;
     bool traversing = false;  // cur holds an unfinished traversal
     bool landed = false;      // cur holds a finished traversal whose result has not been consumed yet
 
@@ -341,8 +345,8 @@ __global__ __launch_bounds__(256) void render_lbvh_kernel(const RenderArgs a) {
         }
         for (uint32_t k = 0; k < kStepsPerRound; ++k) {
             if (traversing) {
-                cursor_step<STATS>(a.bvh, cur, wc.disc, wc.nodes, wc.leaves);
-                if (cur.node >= a.bvh.n_nodes) {
+                cursor_step<STATS>(a.bvh, cur, stack, 256u, wc.disc, wc.nodes, wc.leaves);
+                if (cur.cur == kCursorDone) {
                     traversing = false;
                     landed = true;
                 }
@@ -461,10 +465,11 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     if (a.n_blocks == 1) a.partials = nullptr;  // single block: the kernel merges into the accumulator itself
     const dim3 grid(a.wgs_per_layer * a.n_blocks), block(256);
     if (accel == kAccelLbvh) {
+        const size_t lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int);
         if (stats) {
-            hipLaunchKernelGGL((render_lbvh_kernel<true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((render_lbvh_kernel<true>), grid, block, lds, stream, a);
         } else {
-            hipLaunchKernelGGL((render_lbvh_kernel<false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((render_lbvh_kernel<false>), grid, block, lds, stream, a);
         }
     } else {
         size_t lds = (size_t)a.n_spheres * sizeof(float4);
@@ -490,7 +495,8 @@ hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream)
     const uint32_t tiles = ((a.w + kTile - 1) / kTile) * ((a.h + kTile - 1) / kTile);
     if (tiles == 0) return hipSuccess;
     if (accel == kAccelLbvh) {
-        hipLaunchKernelGGL(primary_hits_kernel<kAccelLbvh>, dim3(tiles * kBlocksPerTile), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(primary_hits_kernel<kAccelLbvh>, dim3(tiles * kBlocksPerTile), dim3(256),
+                           (size_t)a.bvh.stack_depth * 256 * sizeof(int), stream, a);
     } else {
         hipLaunchKernelGGL(primary_hits_kernel<kAccelLinear>, dim3(tiles * kBlocksPerTile), dim3(256),
                            (size_t)a.n_spheres * sizeof(float4), stream, a);

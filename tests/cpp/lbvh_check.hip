@@ -32,17 +32,19 @@ int main(int argc, char** argv) {
     std::vector<float4> lin(n);
     for (uint32_t i = 0; i < n; ++i) lin[i] = make_float4(sph[4 * i], sph[4 * i + 1], sph[4 * i + 2], sph[4 * i + 3] * sph[4 * i + 3]);
     pt::LbvhView v;
-    v.nodes = (const float4*)t.nodes.data();
+    v.wide = (const float4*)t.wide.data();
     v.leaf_spheres = (const float4*)t.leaf_spheres.data();
     v.leaf_index = t.leaf_index.data();
-    v.n_nodes = (uint32_t)t.nodes.size();
+    v.stack_depth = t.stack_depth;
+    if (t.stack_depth > pt::kMaxStack) { printf("stack depth %u exceeds kMaxStack\n", t.stack_depth); return 1; }
+    int stack[pt::kMaxStack];
     unsigned long long visits = 0, leaves = 0, hits = 0;
     for (size_t r = 0; r < m; ++r) {
         const float* p = &rays[6 * r];
         pt::f3 o = pt::mk3(p[0], p[1], p[2]), d = pt::mk3(p[3], p[4], p[5]);
         uint32_t dp0 = 0, dp1 = 0, nv = 0, lt = 0;
         pt::HitRec a = pt::trace_linear<false>(lin.data(), n, o, d, dp0);
-        pt::HitRec b = pt::trace_lbvh<true>(v, o, d, dp1, nv, lt);
+        pt::HitRec b = pt::trace_lbvh<true>(v, stack, 1u, o, d, dp1, nv, lt);
         visits += nv; leaves += lt; hits += a.idx >= 0;
         if (a.idx != b.idx || memcmp(&a.t, &b.t, 4) != 0) {
             printf("MISMATCH ray %zu: scan (%d, %.9g) lbvh (%d, %.9g)\n", r, a.idx, a.t, b.idx, b.t);
@@ -50,6 +52,6 @@ int main(int argc, char** argv) {
         }
     }
     printf("ok %zu rays, %u spheres, %zu nodes, depth %u, hits %llu, mean node visits %.1f, mean leaf tests %.1f\n", m, n,
-           t.nodes.size(), t.max_depth, hits, (double)visits / m, (double)leaves / m);
+           t.wide.size(), t.max_depth, hits, (double)visits / m, (double)leaves / m);
     return 0;
 }
