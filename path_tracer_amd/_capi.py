@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libinsploray_hip.so")
+LIB_PATH = os.environ.get("IR_DEBUG_LIB") or os.path.join(_HERE, "lib", "libinsploray_hip.so")  # IR_DEBUG_LIB: A/B builds in tools/
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

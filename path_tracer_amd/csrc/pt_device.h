@@ -391,64 +391,65 @@ PT_DEV bool padded_box_hit(const LbvhCursor& c, float4 lo, float4 hi, float& tmi
     const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
     return (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= c.best);
 }
-// one step: visit the current inner node (test both children, enter the nearer, push the farther) and, if that
-// leads to a leaf, test its <= kLeafMax spheres and pop.  Precondition: c.cur != kCursorDone.
+PT_DEV int cursor_pop(LbvhCursor& c, const int* stack, uint32_t stride) {
+    if (c.sp == 0) return kCursorDone;
+    c.sp--;
+    return stack[c.sp * stride];
+}
+// Precondition: c.cur >= 0 (inner node).  Tests both children, enters the nearer hit child and pushes the farther;
+// with no child hit, pops.  Afterwards c.cur is an inner node, a leaf (< 0) or kCursorDone.
+template <bool STATS>
+PT_DEV void cursor_inner_step(const LbvhView& v, LbvhCursor& c, int* stack, uint32_t stride, uint32_t& node_visits) {
+    const size_t at = 4 * (size_t)c.cur;
+    const float4 n0 = v.wide[at], n1 = v.wide[at + 1], n2 = v.wide[at + 2], n3 = v.wide[at + 3];
+    if (STATS) node_visits += 2;  // two box tests
+    float tl, tr;
+    const bool hl = padded_box_hit(c, n0, n1, tl), hr = padded_box_hit(c, n2, n3, tr);
+    const int rl = __builtin_bit_cast(int, n0.w), rr = __builtin_bit_cast(int, n1.w);
+    if (hl && hr) {
+        const bool right_first = tr < tl;
+        stack[c.sp * stride] = right_first ? rl : rr;
+        c.sp++;
+        c.cur = right_first ? rr : rl;
+    } else if (hl) {
+        c.cur = rl;
+    } else if (hr) {
+        c.cur = rr;
+    } else {
+        c.cur = cursor_pop(c, stack, stride);
+    }
+}
+// Precondition: c.cur < 0 (leaf).  Tests its <= kLeafMax spheres with the scan's arithmetic, then pops.
+template <bool STATS>
+PT_DEV void cursor_leaf_step(const LbvhView& v, LbvhCursor& c, const int* stack, uint32_t stride, uint32_t& disc_pos, uint32_t& leaf_tests) {
+    const uint32_t leaf = (uint32_t)(-(c.cur + 1));
+    const uint32_t first = leaf >> 3, count = leaf & 7u;
+    const f3 o = c.o, d = c.d;
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 s = v.leaf_spheres[first + k];
+        if (STATS) leaf_tests++;
+        f3 oc = o - mk3(s.x, s.y, s.z);
+        float b = 2.0f * dot(d, oc);
+        float cc = dot(oc, oc) - s.w;
+        float disc = b * b - c.a4 * cc;
+        if (disc < 0.0f) continue;
+        if (STATS) disc_pos++;
+        float sq = sqrt_cr(disc);
+        float t = (-b - sq) / c.a2;
+        const int orig = v.leaf_index[first + k];
+        if (t > 0.0f && (t < c.best || (t == c.best && orig < c.idx))) {
+            c.idx = orig;
+            c.best = t;
+        }
+    }
+    c.cur = cursor_pop(c, stack, stride);
+}
+// one step of a traversal run on its own: the inner node and, if that leads to a leaf, the leaf
 template <bool STATS>
 PT_DEV void cursor_step(const LbvhView& v, LbvhCursor& c, int* stack, uint32_t stride, uint32_t& disc_pos, uint32_t& node_visits,
                         uint32_t& leaf_tests) {
-    int cur = c.cur;
-    if (cur >= 0) {
-        const float4 n0 = v.wide[4 * (size_t)cur], n1 = v.wide[4 * (size_t)cur + 1];
-        const float4 n2 = v.wide[4 * (size_t)cur + 2], n3 = v.wide[4 * (size_t)cur + 3];
-        if (STATS) node_visits += 2;  // two box tests
-        float tl, tr;
-        const bool hl = padded_box_hit(c, n0, n1, tl), hr = padded_box_hit(c, n2, n3, tr);
-        const int rl = __builtin_bit_cast(int, n0.w), rr = __builtin_bit_cast(int, n1.w);
-        if (hl && hr) {
-            const bool right_first = tr < tl;
-            stack[c.sp * stride] = right_first ? rl : rr;
-            c.sp++;
-            cur = right_first ? rr : rl;
-        } else if (hl) {
-            cur = rl;
-        } else if (hr) {
-            cur = rr;
-        } else if (c.sp > 0) {
-            c.sp--;
-            cur = stack[c.sp * stride];
-        } else {
-            cur = kCursorDone;
-        }
-    }
-    if (cur < 0) {
-        const uint32_t leaf = (uint32_t)(-(cur + 1));
-        const uint32_t first = leaf >> 3, count = leaf & 7u;
-        const f3 o = c.o, d = c.d;
-        for (uint32_t k = 0; k < count; ++k) {
-            const float4 s = v.leaf_spheres[first + k];
-            if (STATS) leaf_tests++;
-            f3 oc = o - mk3(s.x, s.y, s.z);
-            float b = 2.0f * dot(d, oc);
-            float cc = dot(oc, oc) - s.w;
-            float disc = b * b - c.a4 * cc;
-            if (disc < 0.0f) continue;
-            if (STATS) disc_pos++;
-            float sq = sqrt_cr(disc);
-            float t = (-b - sq) / c.a2;
-            const int orig = v.leaf_index[first + k];
-            if (t > 0.0f && (t < c.best || (t == c.best && orig < c.idx))) {
-                c.idx = orig;
-                c.best = t;
-            }
-        }
-        if (c.sp > 0) {
-            c.sp--;
-            cur = stack[c.sp * stride];
-        } else {
-            cur = kCursorDone;
-        }
-    }
-    c.cur = cur;
+    if (c.cur >= 0) cursor_inner_step<STATS>(v, c, stack, stride, node_visits);
+    if (c.cur < 0) cursor_leaf_step<STATS>(v, c, stack, stride, disc_pos, leaf_tests);
 }
 
 template <bool STATS>

@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
 // traversing), so short rays do not sit out long ones: they go on to their next ray.  Every lane still runs its own
 // pixel's samples in order, so per-pixel sums are unchanged.
 // ----------------------------------------------------------------------------------------------------
-constexpr uint32_t kShadeBatch = 24;   // run the shading block when this many lanes wait for it
-constexpr uint32_t kStepsPerRound = 4; // traversal steps between two looks at the wave's state
+constexpr uint32_t kShadeBatch = 32;   // run the shading block when this many lanes wait for it
+constexpr uint32_t kStepsPerRound = 8; // traversal steps between two looks at the wave's state
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_lbvh_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(256, 6) void render_lbvh_kernel(const RenderArgs a) {
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
     const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;

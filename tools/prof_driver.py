@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Minimal driver for rocprofv3 passes: renders one configuration a few times through the C ABI (no torch).
-usage: prof_driver.py [c1|c2|c3] [reps] [spp]"""
+usage: prof_driver.py [c1|c2|c3] [reps] [spp] [sample_block]"""
 import os
 import sys
 
@@ -22,6 +22,8 @@ if len(sys.argv) > 3:
 rt = pta.RayTracer(0, 0, device=0)
 rt.set_active_camera(cam)
 rt.set_integrator(bounces=8, max_compulsory_bounces=2, seed=W.RNG_SEED)
+if len(sys.argv) > 4:
+    rt.set_sample_block(int(sys.argv[4]))
 for _ in range(reps):
     rt.render(scene, w, h, False, spp=spp)
     ms, n = rt.last_kernel_ms()
