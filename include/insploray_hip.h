@@ -83,7 +83,7 @@ int ir_set_sky_filter(ir_context* ctx, int filter);
 /* Closest-hit structure: IR_ACCEL_LINEAR = the reference's linear scan (integrator.rs:106-127) over an
  * LDS-staged SoA buffer (at most 10 000 spheres); IR_ACCEL_LBVH = linear BVH over the spheres whose (t, index)
  * equals the scan's bit for bit (leaf tests are the scan's arithmetic, node tests are conservative, ties keep the
- * lowest index); IR_ACCEL_AUTO (default) = scan below 48 spheres, LBVH from there. */
+ * lowest index); IR_ACCEL_AUTO (default) = scan below 64 spheres (the measured crossover), LBVH from there. */
 int ir_set_accel(ir_context* ctx, int accel);
 /* What the next launch will use for the current scene: *out_accel = IR_ACCEL_LINEAR or IR_ACCEL_LBVH, LBVH node
  * count and depth (0 for the scan).  Builds the LBVH if it is selected and stale.  Any pointer may be NULL. */

@@ -198,7 +198,7 @@ int rebuild_shade(ir_context* ctx) {
 
 // Which closest-hit structure the next launch uses.  AUTO: the LDS scan up to kAutoLbvhFrom spheres (for a handful
 // of spheres a tree only adds node tests), the LBVH above; more than kMaxLdsSpheres cannot be staged in LDS at all.
-constexpr uint32_t kAutoLbvhFrom = 48;
+constexpr uint32_t kAutoLbvhFrom = 64;  // measured crossover, tools/accel_crossover.py
 constexpr uint32_t kMaxSpheres = 1u << 24;  // leaf = first * 8 + count must stay a non-negative int32
 int selected_accel(const ir_context* ctx) {
     if (ctx->n_spheres > pt::kMaxLdsSpheres) return pt::kAccelLbvh;

@@ -1,0 +1,128 @@
+"""Edge cases of the render path on the GPU against the oracle (bitwise): empty and degenerate inputs, the reference's
+quirks (default material, near-root-only intersection, ties), odd frame shapes, rotated cameras."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x0123456789ABCDEF
+
+
+@pytest.fixture(scope="module")
+def pta():
+    import path_tracer_amd
+    return path_tracer_amd
+
+
+@pytest.fixture(scope="module")
+def tracer(pta):
+    rt = pta.RayTracer(0, 0, device=0)
+    yield rt
+    rt.close()
+
+
+def _compare(pta, tracer, oracle, scene, cam, w, h, spp, bounces=5, rr=2, accel=None):
+    from path_tracer_amd import _capi
+    tracer.set_active_camera(cam)
+    tracer.set_integrator(bounces=bounces, max_compulsory_bounces=rr, seed=SEED)
+    tracer.set_accel(accel if accel is not None else _capi.IR_ACCEL_AUTO)
+    try:
+        tracer.render(scene, w, h, False, spp=spp)
+        s, c = tracer.get_radiance()
+        idx, t = tracer.get_primary_hits(with_t=True)
+    finally:
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    oc = oracle.camera_from(cam, w, h)
+    os_, ocnt, _, _ = oracle.render(oc, scene, spp, bounces=bounces, rr_start=rr, seed=SEED, math_mode=1)
+    oidx, ot = oracle.primary_hits(oc, scene)
+    assert np.array_equal(c, ocnt)
+    assert idx.tobytes() == oidx.tobytes() and t.tobytes() == ot.tobytes()
+    assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.nanmax(np.abs(s - os_))}"
+    return s, idx
+
+
+def test_empty_scene_is_all_sky(pta, tracer, oracle):
+    from path_tracer_amd import workloads as W
+    scene = pta.Scene(default_sky_color=(0.25, 0.5, 0.75))
+    s, idx = _compare(pta, tracer, oracle, scene, W.default_camera(70, 40), 70, 40, 3)
+    assert (idx == -1).all() and np.allclose(s[..., :3], np.array([0.75, 1.5, 2.25], dtype=np.float32))
+    scene.skybox = W.synthetic_sky(64, 32)
+    _compare(pta, tracer, oracle, scene, W.default_camera(70, 40), 70, 40, 3)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 37), (130, 1), (65, 17), (257, 129)])
+def test_odd_frame_shapes(pta, tracer, oracle, w, h):
+    from path_tracer_amd import workloads as W
+    _compare(pta, tracer, oracle, W.scene_s1(), W.default_camera(w, h), w, h, 5, bounces=8)
+
+
+def test_zero_sized_and_zero_sample_renders_are_no_ops(pta, tracer):
+    from path_tracer_amd import workloads as W
+    scene = W.scene_s1(skybox=None)
+    tracer.set_active_camera(W.default_camera(0, 0))
+    tracer.render(scene, 0, 0, False)                      # RayTracer::new(0, 0) then render(.., 0, 0, ..)
+    assert tracer.get_current_size() == [0, 0] and tracer.get_output().size == 0
+    tracer.set_active_camera(W.default_camera(32, 16))
+    tracer.render(scene, 32, 16, False, spp=0)
+    s, c = tracer.get_radiance()
+    assert not s.any() and not c.any() and (tracer.get_output() == 0).all()   # unrendered pixel resolves to 0x00000000
+
+
+def test_default_material_for_bad_ids(pta, tracer, oracle):
+    """material_id < 0 or out of range => DEFAULT_MATERIAL, white Lambertian (integrator.rs:8-14,53-60)."""
+    from path_tracer_amd import workloads as W
+    scene = W.scene_s1(skybox=None)
+    scene.spheres[0].material_id = -1
+    scene.spheres[2].material_id = 99
+    s, _ = _compare(pta, tracer, oracle, scene, W.default_camera(96, 54), 96, 54, 6, bounces=8)
+    scene.materials = []                                    # no materials at all
+    _compare(pta, tracer, oracle, scene, W.default_camera(96, 54), 96, 54, 6, bounces=8)
+
+
+def test_camera_inside_a_sphere_sees_through_it(pta, tracer, oracle):
+    """Only the near root is tested (integrator.rs:121): from inside, a sphere is invisible."""
+    from path_tracer_amd import workloads as W
+    scene = W.scene_s1(skybox=None)
+    scene.spheres[0].radius = 3.0                           # camera at (0,0,2) is now inside sphere 0
+    _, idx = _compare(pta, tracer, oracle, scene, W.default_camera(64, 36), 64, 36, 4)
+    assert not (idx == 0).any()
+
+
+@pytest.mark.parametrize("accel", ["linear", "lbvh"])
+def test_coincident_spheres_keep_lowest_index(pta, tracer, oracle, accel):
+    """Strict '<' in the scan (integrator.rs:121): among identical spheres the first one wins, with either structure."""
+    from path_tracer_amd import _capi, workloads as W
+    base = W.scene_s2(n=40)
+    xyzr, mid = base.flat_spheres()
+    xyzr = np.concatenate([xyzr, xyzr[5:25], xyzr[5:25]], 0)          # two more copies of 20 spheres
+    mid = np.concatenate([mid, (mid[5:25] + 1) % 64, (mid[5:25] + 2) % 64], 0)   # with other materials: order matters
+    scene = pta.FlatScene(xyzr, mid, base.flat_materials(), default_sky_color=(0.6, 0.7, 0.9))
+    s, idx = _compare(pta, tracer, oracle, scene, W.camera_s2(160, 90), 160, 90, 4, bounces=8,
+                      accel=_capi.IR_ACCEL_LINEAR if accel == "linear" else _capi.IR_ACCEL_LBVH)
+    assert idx.max() < 40
+
+
+def test_rotated_camera_pose(pta, tracer, oracle):
+    """The Blender pose of the reference's own camera test (pinhole_camera.rs:162-239) through the whole path."""
+    from path_tracer_amd import workloads as W
+    cam = pta.PinholeCamera((-2.4027, -2.5716, 3.5259), (0.1975, -0.7941, -1.9074), 35.0, 55.0, [120, 80])
+    scene = W.scene_s1()
+    for sp in scene.spheres:
+        sp.position = [sp.position[0], sp.position[2], sp.position[1]]   # any scene the pose looks at
+    _compare(pta, tracer, oracle, scene, cam, 120, 80, 4, bounces=8)
+
+
+@pytest.mark.parametrize("bounces,rr", [(0, 2), (1, 0), (2, 0), (16, 0), (16, 16)])
+def test_depth_and_roulette_extremes(pta, tracer, oracle, bounces, rr):
+    from path_tracer_amd import workloads as W
+    s, _ = _compare(pta, tracer, oracle, W.scene_s1(), W.default_camera(80, 45), 80, 45, 6, bounces=bounces, rr=rr)
+    if bounces == 0:
+        assert not s[..., :3].any() and (s[..., 3] == 6).all()     # integrator.rs:47,92: (0,0,0,1) per sample
+
+
+def test_lbvh_radiance_on_mid_sized_scene(pta, tracer, oracle):
+    """A scene just above the AUTO crossover: the LBVH kernel's scheduling must not change any sample."""
+    from path_tracer_amd import _capi, workloads as W
+    scene = W.scene_s2(n=200)
+    _compare(pta, tracer, oracle, scene, W.camera_s2(128, 72), 128, 72, 20, bounces=8)
+    assert tracer.get_accel_info()["accel"] == _capi.IR_ACCEL_LBVH
