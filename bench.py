@@ -78,6 +78,9 @@ def main():
                          "sample indices, per-GPU spp fixed (weak scaling). tiles (default for c4): 64x64 tiles dealt "
                          "round-robin, total work fixed (strong scaling). Both end in one RCCL reduce(sum) to rank 0.")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a box with ONE GPU: every rank uses device 0 and the exchange step goes "
+                         "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,9 +95,14 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import path_tracer_amd as pta
     from path_tracer_amd import _capi, workloads as Wk
@@ -129,6 +137,9 @@ def main():
     sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     counts = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     _capi.check(rt._ctx, _capi.lib.ir_bind_accumulator(rt._ctx, sums.data_ptr(), counts.data_ptr(), W, H))
+    # launch on torch's current stream: the RCCL reduce (ordered against that stream by torch.distributed) and the
+    # next step's accumulator reset are then ordered by the stream, not by luck
+    _capi.check(rt._ctx, _capi.lib.ir_set_stream(rt._ctx, torch.cuda.current_stream().cuda_stream))
     partition = args.partition or ("tiles" if args.workload == "c4" else "samples")
     if world > 1:
         rt.set_partition(_capi.IR_PARTITION_TILES if partition == "tiles" else _capi.IR_PARTITION_SAMPLES, rank, world)
@@ -140,7 +151,14 @@ def main():
     def step():
         rt.render(scene, W, H, False, spp=spp)  # blocks until the launches are done
         kernel_ms.append(rt.last_kernel_ms())
-        if world > 1:
+        if world > 1 and args.rehearse_one_gpu:
+            hs, hc = sums.cpu(), counts.cpu()
+            dist.reduce(hs, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(hc, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                sums.copy_(hs)
+                counts.copy_(hc)
+        elif world > 1:
             dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
             dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
 
@@ -160,7 +178,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

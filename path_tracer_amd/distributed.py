@@ -64,6 +64,9 @@ class DistributedFilm:
         self.counts = torch.zeros((height, width), dtype=torch.int32, device="cuda")
         _capi.check(tracer._ctx, _capi.lib.ir_bind_accumulator(tracer._ctx, self.sums.data_ptr(),
                                                               self.counts.data_ptr(), width, height))
+        # launch on torch's current stream so that the collective (which torch.distributed orders against that stream)
+        # and the next render's accumulator reset cannot overlap
+        _capi.check(tracer._ctx, _capi.lib.ir_set_stream(tracer._ctx, torch.cuda.current_stream().cuda_stream))
         tracer.set_partition(mode if self.world > 1 else _capi.IR_PARTITION_NONE, self.rank, self.world)
 
     def combine(self, dst=0, all_ranks=False):
