@@ -216,6 +216,27 @@ public:
     uint64_t seed = 0x0123456789ABCDEFull;
     ir_context* raw() { return ctx_; }
 
+    // ---- extensions the reference does not have (each one call into the C ABI)
+    void set_sky_filter(int filter) { check(ir_set_sky_filter(ctx_, filter)); }              // IR_SKY_NEAREST == exr.rs:20-23
+    void set_accel(int accel) { check(ir_set_accel(ctx_, accel)); }                          // IR_ACCEL_AUTO / LINEAR / LBVH
+    void set_sample_block(uint32_t samples) { check(ir_set_sample_block(ctx_, samples)); }
+    void set_partition(int mode, uint32_t rank, uint32_t world) { check(ir_set_partition(ctx_, mode, rank, world)); }
+    uint32_t samples_accumulated() const { return ir_samples_accumulated(ctx_); }
+    // Accumulator.framebuffer / sample_counts (full_buffer.rs:7-12): n x 4 floats, n x u32
+    void get_radiance(std::vector<float>& sum_rgba, std::vector<uint32_t>& counts) {
+        auto sz = get_current_size();
+        size_t n = (size_t)sz[0] * sz[1];
+        sum_rgba.assign(n * 4, 0.0f);
+        counts.assign(n, 0u);
+        if (n) check(ir_get_radiance(ctx_, sum_rgba.data(), counts.data(), n));
+    }
+    std::vector<int32_t> get_primary_hits() {
+        auto sz = get_current_size();
+        std::vector<int32_t> idx((size_t)sz[0] * sz[1]);
+        if (!idx.empty()) check(ir_get_primary_hits(ctx_, idx.data(), nullptr, idx.size()));
+        return idx;
+    }
+
 private:
     void check(int rc) const {
         if (rc != IR_OK) throw Error(rc, ir_last_error(ctx_));

@@ -47,6 +47,19 @@ int main(int argc, char** argv) {
         const auto& px = rt.get_output();
         CHECK(px.size() == 64 * 36 && (px[0] >> 24) == 0xBA);
         CHECK(rt.get_current_size()[0] == 64);
+        // extensions: 4 samples in one call on a fresh frame == the four reference-style calls above (bitwise)
+        std::vector<float> four_calls, one_call;
+        std::vector<uint32_t> counts;
+        rt.get_radiance(four_calls, counts);
+        CHECK(rt.samples_accumulated() == 4 && counts[100] == 4);
+        rt.set_sample_block(128);
+        rt.set_sky_filter(IR_SKY_NEAREST);
+        rt.set_accel(IR_ACCEL_AUTO);
+        rt.render(s, 64, 36, false, 4);
+        rt.get_radiance(one_call, counts);
+        CHECK(std::memcmp(four_calls.data(), one_call.data(), one_call.size() * sizeof(float)) == 0);
+        auto hits = rt.get_primary_hits();
+        CHECK(hits.size() == 64 * 36 && hits[18 * 64 + 32] == 0 && hits[0] == 1 && hits[35 * 64] == -1);
         std::printf("gpu render ok, %f s\n", rt.get_last_render_time().count());
     } else {
         threw = false;
