@@ -12,7 +12,7 @@
 
 namespace pt {
 
-constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kLeafMax = 2;
 
 // 32 bytes.  Pre-order layout: the first child of an inner node is node+1; `skip` is the next node in pre-order after
 // this node's subtree (== node count at the end).  leaf < 0 => inner node; else leaf = first * 8 + count into the
