@@ -78,6 +78,8 @@ def main():
                          "sample indices, per-GPU spp fixed (weak scaling). tiles (default for c4): 64x64 tiles dealt "
                          "round-robin, total work fixed (strong scaling). Both end in one RCCL reduce(sum) to rank 0.")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
+    ap.add_argument("--schedule", choices=["auto", "regeneration", "wavefront"], default="auto",
+                    help="integrator schedule (ir_set_schedule); results are identical, only speed differs")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a box with ONE GPU: every rank uses device 0 and the exchange step goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
@@ -132,6 +134,8 @@ def main():
     rt = pta.RayTracer(0, 0, device=local_rank)
     rt.set_active_camera(cam)
     rt.set_integrator(bounces=BOUNCES, max_compulsory_bounces=RR, seed=Wk.RNG_SEED)
+    rt.set_schedule({"auto": _capi.IR_SCHEDULE_AUTO, "regeneration": _capi.IR_SCHEDULE_REGENERATION,
+                     "wavefront": _capi.IR_SCHEDULE_WAVEFRONT}[args.schedule])
     rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
     # accumulator in torch-owned device memory so that RCCL can reduce it in place
     sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")

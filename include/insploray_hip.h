@@ -42,6 +42,7 @@ enum {
 enum { IR_SKY_NEAREST = 0, IR_SKY_BILINEAR = 1 };  /* exr.rs:20-23 is NEAREST */
 enum { IR_PARTITION_NONE = 0, IR_PARTITION_TILES = 1, IR_PARTITION_SAMPLES = 2 };
 enum { IR_ACCEL_AUTO = 0, IR_ACCEL_LINEAR = 1, IR_ACCEL_LBVH = 2 };
+enum { IR_SCHEDULE_AUTO = 0, IR_SCHEDULE_REGENERATION = 1, IR_SCHEDULE_WAVEFRONT = 2 };
 
 /* ABI version of this header (bumped on incompatible change). */
 uint32_t ir_abi_version(void);
@@ -124,6 +125,17 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
  * one call fill the GPU.  On a zeroed accumulator a call with spp <= samples_per_block is bit-identical to spp
  * successive reference-style 1-sample calls. */
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);
+
+/* How the integrator is scheduled on the GPU (results are identical bit for bit, only speed differs):
+ *   IR_SCHEDULE_REGENERATION : one kernel; a lane owns a pixel and runs its samples in order, restarting at the
+ *                              primary hit when a path ends; path state never leaves the registers;
+ *   IR_SCHEDULE_WAVEFRONT    : one kernel per stage (primary, generate, one per bounce, commit); paths stream
+ *                              through queues in device memory and are compacted between bounces with a wave64
+ *                              ballot/prefix count; max_paths bounds the queue memory (60 B per path and queue,
+ *                              16 B per path for the per-sample values; 0 keeps the default of 32 Mi paths);
+ *   IR_SCHEDULE_AUTO         : the faster one for the scene as measured on MI355X.
+ * Renders that collect statistics (ir_enable_stats) always use REGENERATION. */
+int ir_set_schedule(ir_context* ctx, int schedule, uint32_t max_paths);
 
 /* Multi-GPU work split for this context (rank in [0, world)).
  *   IR_PARTITION_TILES  : 64x64 tiles (renderer.rs:105-119) dealt round-robin; this rank renders tile t iff

@@ -23,6 +23,7 @@ IR_EINVAL, IR_EDEVICE, IR_ESTATE, IR_ENOMEM, IR_EIO, IR_ELIMIT = -1, -2, -3, -4,
 IR_SKY_NEAREST, IR_SKY_BILINEAR = 0, 1
 IR_PARTITION_NONE, IR_PARTITION_TILES, IR_PARTITION_SAMPLES = 0, 1, 2
 IR_ACCEL_AUTO, IR_ACCEL_LINEAR, IR_ACCEL_LBVH = 0, 1, 2
+IR_SCHEDULE_AUTO, IR_SCHEDULE_REGENERATION, IR_SCHEDULE_WAVEFRONT = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
 c_i32_p = C.POINTER(C.c_int32)
@@ -52,6 +53,7 @@ PROTOTYPES = {
     "ir_pinhole_get_ray": (C.c_int, [c_float_p, c_float_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                      C.c_uint32, C.c_uint32, c_float_p]),
     "ir_set_integrator": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "ir_set_schedule": (C.c_int, [ctx_p, C.c_int, C.c_uint32]),
     "ir_set_sample_block": (C.c_int, [ctx_p, C.c_uint32]),
     "ir_set_partition": (C.c_int, [ctx_p, C.c_int, C.c_uint32, C.c_uint32]),
     "ir_render": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),

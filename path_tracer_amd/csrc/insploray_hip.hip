@@ -68,6 +68,10 @@ struct ir_context {
     uint32_t bounces = 5, rr_start = 2;
     uint32_t sample_block = 128;
     DeviceBuf d_partials;
+    // wavefront schedule: path queues and per-sample values (allocated on first use)
+    int schedule = IR_SCHEDULE_AUTO;
+    uint32_t wf_max_paths = 32u << 20;
+    DeviceBuf d_wf_queue[2], d_wf_counts, d_wf_values, d_wf_prim, d_wf_tileacc;
     uint64_t seed = 0x0123456789ABCDEFull;
 
     // partition
@@ -300,6 +304,7 @@ int ir_create(ir_context** out_ctx, int device) {
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = pt::init_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
+    if ((e = pt::init_wavefront_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
     *out_ctx = ctx;
     return IR_OK;
 }
@@ -311,6 +316,8 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_rays);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
     release(ctx->d_stats); release(ctx->d_partials);
+    release(ctx->d_wf_queue[0]); release(ctx->d_wf_queue[1]); release(ctx->d_wf_counts); release(ctx->d_wf_values);
+    release(ctx->d_wf_prim); release(ctx->d_wf_tileacc);
     release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -437,6 +444,16 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
     return IR_OK;
 }
 
+int ir_set_schedule(ir_context* ctx, int schedule, uint32_t max_paths) {
+    if (!ctx) return IR_EINVAL;
+    if (schedule != IR_SCHEDULE_AUTO && schedule != IR_SCHEDULE_REGENERATION && schedule != IR_SCHEDULE_WAVEFRONT)
+        return fail(ctx, IR_EINVAL, "ir_set_schedule: unknown schedule %d", schedule);
+    if (max_paths != 0 && max_paths < 65536u) return fail(ctx, IR_EINVAL, "ir_set_schedule: max_paths %u below 65536", max_paths);
+    ctx->schedule = schedule;
+    if (max_paths) ctx->wf_max_paths = max_paths;
+    return IR_OK;
+}
+
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block) {
     if (!ctx) return IR_EINVAL;
     if (samples_per_block == 0 || samples_per_block > 4096)
@@ -518,6 +535,55 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     uint64_t base = ctx->samples_done;
     if (ctx->part_mode == IR_PARTITION_SAMPLES) base = (uint64_t)ctx->samples_done * ctx->world + (uint64_t)ctx->rank * spp;
     if (base + spp > 0xffffffffull) return fail(ctx, IR_ELIMIT, "ir_render: sample index overflow");
+
+    if (ctx->schedule == IR_SCHEDULE_WAVEFRONT && !ctx->stats_enabled) {
+        // queues sized for at least one sample of every owned pixel (rounded to whole 64x64 tiles)
+        const uint32_t owned = pt::owned_tiles(a.n_tiles, a.tile_rank, a.tile_world);
+        const size_t owned_pixels = (size_t)owned * pt::kTile * pt::kTile;
+        size_t cap = ctx->wf_max_paths;
+        if (cap < owned_pixels) cap = owned_pixels;
+        if (cap > 0xfffffff0u) return fail(ctx, IR_ELIMIT, "ir_render: wavefront queue capacity overflow");
+        size_t per_batch = owned_pixels ? cap / owned_pixels : 1;
+        if (per_batch > ctx->sample_block) per_batch = ctx->sample_block;
+        if (per_batch > spp) per_batch = spp;
+        pt::WfArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        for (int k = 0; k < 2; ++k) IR_TRY(ensure(ctx, ctx->d_wf_queue[k], cap * (3 + 12) * sizeof(uint32_t)));
+        IR_TRY(ensure(ctx, ctx->d_wf_counts, 2 * sizeof(uint32_t)));
+        IR_TRY(ensure(ctx, ctx->d_wf_values, per_batch * n * sizeof(float4)));
+        IR_TRY(ensure(ctx, ctx->d_wf_prim, 2 * n * sizeof(float4)));
+        IR_TRY(ensure(ctx, ctx->d_wf_tileacc, n * sizeof(float4)));
+        auto queue = [&](int k) {
+            pt::WfQueue q;
+            uint32_t* base = (uint32_t*)ctx->d_wf_queue[k].p;
+            q.pix = base;
+            q.smp = base + cap;
+            q.idx = (int32_t*)(base + 2 * cap);
+            q.f = (float*)(base + 3 * cap);
+            q.count = (uint32_t*)ctx->d_wf_counts.p + k;
+            q.cap = (uint32_t)cap;
+            return q;
+        };
+        wa.r = a;
+        wa.r.spp = spp;
+        wa.r.sample_base = (uint32_t)base;
+        wa.r.sample_block = ctx->sample_block;
+        wa.prim_pos = (float4*)ctx->d_wf_prim.p;
+        wa.prim_nrm = (float4*)ctx->d_wf_prim.p + n;
+        wa.values = (float4*)ctx->d_wf_values.p;
+        wa.tileacc = (float4*)ctx->d_wf_tileacc.p;
+        wa.qin = queue(0);
+        wa.qout = queue(1);
+        // launch_wavefront batches by qin.cap / owned pixels: make that equal to per_batch
+        wa.qin.cap = wa.qout.cap = (uint32_t)(per_batch * owned_pixels);
+        IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        IR_HIP(ctx, pt::launch_wavefront(wa, accel, 256 * 8, ctx->stream));
+        IR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        ctx->events_recorded = true;
+        ctx->last_launches = 1;
+        ctx->samples_done += spp;
+        return IR_OK;
+    }
 
     // bound the work of one launch (pixels x spheres x samples) so that a launch stays well under a second
     const double unit = (double)n * (double)(accel == pt::kAccelLbvh ? 64 : (ctx->n_spheres < 8 ? 8 : ctx->n_spheres));

@@ -63,6 +63,63 @@ struct HitsArgs {
     float* out_t;  // may be nullptr
 };
 
+// ---- helpers shared by the kernel translation units (pt_kernels.hip, pt_wavefront.hip)
+PT_DEV f3 sky_eval(const RenderArgs& a, f3 dir) {
+    if (a.skybox) {
+        if (a.sky_filter == 1) return sky_bilinear(a.skybox, a.sky_w, a.sky_h, dir);  // IR_SKY_BILINEAR
+        return sky_nearest(a.skybox, a.sky_w, a.sky_h, dir);
+    }
+    return mk3(a.sky[0], a.sky[1], a.sky[2]);
+}
+#if defined(__HIPCC__)
+// (x, y) of this lane: workgroup `wg` of a 1D grid over the 16x16 blocks of the owned 64x64 tiles; waves are 8x8 pixels.
+__device__ __forceinline__ bool lane_pixel(uint32_t wg, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world, uint32_t w,
+                                           uint32_t h, uint32_t& x, uint32_t& y) {
+    const uint32_t k = wg / kBlocksPerTile;
+    const uint32_t sub = wg % kBlocksPerTile;
+    const uint32_t tile = tile_rank + k * tile_world;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    x = tx * kTile + (sub & 3) * kBlockEdge + (wave & 1) * 8 + (lane & 7);
+    y = ty * kTile + (sub >> 2) * kBlockEdge + (wave >> 1) * 8 + (lane >> 3);
+    return x < w && y < h;
+}
+__device__ __forceinline__ void stage_spheres(float4* s_sph, const float4* __restrict__ g, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float4 s = g[i];
+        s.w = s.w * s.w;  // radius * radius (integrator.rs:111), same product evaluated once
+        s_sph[i] = s;
+    }
+    __syncthreads();
+}
+#endif
+__host__ __device__ inline uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) {
+    return rank < n_tiles ? (n_tiles - rank + world - 1) / world : 0;
+}
+
+// ---- wavefront pipeline (pt_wavefront.hip)
+struct WfQueue {         // SoA path records in device memory
+    uint32_t* pix;       // pixel index
+    uint32_t* smp;       // sample index inside the batch
+    int32_t* idx;        // sphere the path sits on
+    float* f;            // 12 planes of `cap` floats: position, normal, contribution, light (xyz each)
+    uint32_t* count;     // entries in the queue (device counter)
+    uint32_t cap;
+};
+struct WfArgs {
+    RenderArgs r;
+    float4* prim_pos;    // per pixel: (primary hit point, bits of the sphere index) or (sky value, -1)
+    float4* prim_nrm;    // per pixel: primary hit normal
+    float4* values;      // [sample of the batch][pixel]: radiance of each finished sample
+    float4* tileacc;     // [pixel]: running sum of the current sample block
+    WfQueue qin, qout;
+    uint32_t batch_first, batch_n;  // samples [batch_first, batch_first + batch_n) of the call
+    uint32_t block_spp;             // samples of the current block
+    uint32_t first_batch, last_batch, depth;
+};
+hipError_t init_wavefront_kernels();
+hipError_t launch_wavefront(const WfArgs& a, int accel, uint32_t bounce_wgs, hipStream_t stream);
+
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 enum { kAccelLinear = 0, kAccelLbvh = 1 };
 constexpr uint32_t kNumStats = 7;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests

@@ -15,36 +15,6 @@ namespace pt {
 
 namespace {
 
-__device__ __forceinline__ f3 sky_eval(const RenderArgs& a, f3 dir) {
-    if (a.skybox) {
-        if (a.sky_filter == 1) return sky_bilinear(a.skybox, a.sky_w, a.sky_h, dir);  // IR_SKY_BILINEAR
-        return sky_nearest(a.skybox, a.sky_w, a.sky_h, dir);
-    }
-    return mk3(a.sky[0], a.sky[1], a.sky[2]);
-}
-
-// (x, y) of this lane: 1D grid over the 16x16 blocks of the owned 64x64 tiles; waves are 8x8 pixels.
-__device__ __forceinline__ bool lane_pixel(uint32_t wg, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world, uint32_t w,
-                                           uint32_t h, uint32_t& x, uint32_t& y) {
-    const uint32_t k = wg / kBlocksPerTile;
-    const uint32_t sub = wg % kBlocksPerTile;
-    const uint32_t tile = tile_rank + k * tile_world;
-    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    x = tx * kTile + (sub & 3) * kBlockEdge + (wave & 1) * 8 + (lane & 7);
-    y = ty * kTile + (sub >> 2) * kBlockEdge + (wave >> 1) * 8 + (lane >> 3);
-    return x < w && y < h;
-}
-
-__device__ __forceinline__ void stage_spheres(float4* s_sph, const float4* __restrict__ g, uint32_t n) {
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        float4 s = g[i];
-        s.w = s.w * s.w;  // radius * radius (integrator.rs:111), same product evaluated once
-        s_sph[i] = s;
-    }
-    __syncthreads();
-}
-
 struct WorkCounters {
     uint32_t disc, nodes, leaves;
 };
@@ -450,10 +420,6 @@ hipError_t init_kernels() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)primary_hits_kernel<kAccelLinear>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     return e;
-}
-
-static uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) {
-    return rank < n_tiles ? (n_tiles - rank + world - 1) / world : 0;
 }
 
 hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStream_t stream) {

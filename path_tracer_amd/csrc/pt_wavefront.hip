@@ -1,0 +1,312 @@
+// pt_wavefront.hip — the integrator as a wavefront pipeline with HBM path queues (IR_SCHEDULE_WAVEFRONT).
+//
+// Same samples, same per-sample radiance, same sums as the regeneration kernels of pt_kernels.hip; what differs is
+// where a path lives between bounces.  One kernel per stage, paths stream through queues in device memory:
+//
+//   wf_primary   one lane per pixel: primary ray + primary closest hit (shared by every sample of the pixel, there
+//                is no jitter, pinhole_camera.rs:81-84) -> per-pixel record (hit point, normal, index | sky value)
+//   wf_bounce    one lane per path, bounce d: emission, hemisphere sample, roulette (integrator.rs:50-81), closest
+//                hit of the bounce ray; a path that ends (miss -> + sky, roulette, bounce budget) writes its radiance
+//                into values[sample][pixel], a surviving path is appended to the next queue.  Bounce 0 needs no
+//                queue: its paths are (sample, pixel) pairs read off the per-pixel record (pixels whose primary ray
+//                misses write the sky value straight away)
+//   wf_commit    one lane per pixel: adds the batch's values IN SAMPLE ORDER to the running block sum (the tile
+//                accumulator, tile_buffer.rs:24-28) and, after the block's last batch, merges it into the frame
+//                (full_buffer.rs:107-125)
+//
+// Live paths are compacted between bounces with a wave64 ballot + prefix count (mbcnt); the waves of a workgroup
+// add up in LDS and the workgroup takes its slots with ONE atomic on the queue's counter.  Queue order depends on scheduling, results do not: every path writes its own values slot, and
+// the sums are formed by wf_commit in sample order.  Queue counters never travel to the host: every stage is a
+// fixed-size grid that strides over *count entries.
+#include "pt_kernels.h"
+
+namespace pt {
+namespace {
+
+
+struct PathRec {
+    uint32_t pix, smp;
+    int idx;
+    f3 pos, nrm, contrib, light;
+};
+
+__device__ __forceinline__ PathRec load_path(const WfQueue& q, uint32_t i) {
+    PathRec p;
+    p.pix = q.pix[i];
+    p.smp = q.smp[i];
+    p.idx = q.idx[i];
+    const size_t c = q.cap;
+    p.pos = mk3(q.f[i], q.f[c + i], q.f[2 * c + i]);
+    p.nrm = mk3(q.f[3 * c + i], q.f[4 * c + i], q.f[5 * c + i]);
+    p.contrib = mk3(q.f[6 * c + i], q.f[7 * c + i], q.f[8 * c + i]);
+    p.light = mk3(q.f[9 * c + i], q.f[10 * c + i], q.f[11 * c + i]);
+    return p;
+}
+
+// Compacting append.  Every thread of the workgroup must call it (it contains barriers): wave ballot + mbcnt give the
+// rank inside the wave, an LDS counter the wave's offset inside the workgroup, one global atomic the workgroup's
+// offset in the queue.  A path is dropped only if the queue is full, which the host's batch sizing rules out.
+__device__ __forceinline__ void append_path(const WfQueue& q, bool live, const PathRec& p, uint32_t* s_cnt) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (threadIdx.x == 0) s_cnt[0] = 0;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    if (live && rank == 0) wave_base = atomicAdd(&s_cnt[0], (uint32_t)__builtin_popcountll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt[1] = s_cnt[0] ? atomicAdd(q.count, s_cnt[0]) : 0u;
+    __syncthreads();
+    if (mask == 0ull) return;
+    wave_base = (uint32_t)__builtin_amdgcn_readlane((int)wave_base, (int)__builtin_ctzll(mask));
+    if (!live) return;
+    const uint32_t i = s_cnt[1] + wave_base + rank;
+    if (i >= q.cap) return;
+    q.pix[i] = p.pix;
+    q.smp[i] = p.smp;
+    q.idx[i] = p.idx;
+    const size_t c = q.cap;
+    q.f[i] = p.pos.x; q.f[c + i] = p.pos.y; q.f[2 * c + i] = p.pos.z;
+    q.f[3 * c + i] = p.nrm.x; q.f[4 * c + i] = p.nrm.y; q.f[5 * c + i] = p.nrm.z;
+    q.f[6 * c + i] = p.contrib.x; q.f[7 * c + i] = p.contrib.y; q.f[8 * c + i] = p.contrib.z;
+    q.f[9 * c + i] = p.light.x; q.f[10 * c + i] = p.light.y; q.f[11 * c + i] = p.light.z;
+}
+
+template <int ACCEL>
+__device__ __forceinline__ HitRec wf_trace(const WfArgs& a, const float4* s_dyn, f3 o, f3 d) {
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    if constexpr (ACCEL == kAccelLbvh) {
+        int* stack = reinterpret_cast<int*>(const_cast<float4*>(s_dyn)) + threadIdx.x;  // dynamic LDS = the stacks
+        return trace_lbvh<false>(a.r.bvh, stack, blockDim.x, o, d, c0, c1, c2);
+    } else {
+        return trace_linear<false>(s_dyn, a.r.n_spheres, o, d, c0);
+    }
+}
+template <int ACCEL>
+__device__ __forceinline__ float4 wf_sphere(const WfArgs& a, const float4* s_dyn, int idx) {
+    if constexpr (ACCEL == kAccelLbvh) {
+        return a.r.spheres[idx];
+    } else {
+        return s_dyn[idx];
+    }
+}
+
+template <int ACCEL>
+__global__ __launch_bounds__(256) void wf_primary(const WfArgs a) {
+    extern __shared__ float4 s_dyn[];
+    if constexpr (ACCEL == kAccelLinear) stage_spheres(s_dyn, a.r.spheres, a.r.n_spheres);
+    uint32_t x, y;
+    if (!lane_pixel(blockIdx.x, a.r.tiles_x, a.r.tile_rank, a.r.tile_world, a.r.w, a.r.h, x, y)) return;
+    const uint32_t pixel = y * a.r.w + x;
+    Ray r0;
+    if (a.r.rays) {
+        const float* p = a.r.rays + 6 * (size_t)pixel;
+        r0.o = mk3(p[0], p[1], p[2]);
+        r0.d = mk3(p[3], p[4], p[5]);
+    } else {
+        r0 = pinhole_ray(a.r.cam, x, y, a.r.w, a.r.h);
+    }
+    const HitRec h0 = wf_trace<ACCEL>(a, s_dyn, r0.o, r0.d);
+    if (h0.idx < 0) {
+        // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89)
+        const f3 l0 = mk3(0.0f, 0.0f, 0.0f) + sky_eval(a.r, r0.d) * mk3(1.0f, 1.0f, 1.0f);
+        a.prim_pos[pixel] = make_float4(l0.x, l0.y, l0.z, __builtin_bit_cast(float, -1));
+        a.prim_nrm[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+        f3 pos0, nrm0;
+        hit_geometry(wf_sphere<ACCEL>(a, s_dyn, h0.idx), r0.o, r0.d, h0.t, pos0, nrm0);
+        a.prim_pos[pixel] = make_float4(pos0.x, pos0.y, pos0.z, __builtin_bit_cast(float, h0.idx));
+        a.prim_nrm[pixel] = make_float4(nrm0.x, nrm0.y, nrm0.z, 0.0f);
+    }
+}
+
+// FIRST: bounce 0, paths = (sample j of the batch, owned pixel) read off the per-pixel record; else paths = a.qin.
+template <int ACCEL, bool FIRST>
+__global__ __launch_bounds__(256) void wf_bounce(const WfArgs a) {
+    extern __shared__ float4 s_dyn[];
+    __shared__ uint32_t s_cnt[2];
+    if constexpr (ACCEL == kAccelLinear) stage_spheres(s_dyn, a.r.spheres, a.r.n_spheres);
+    const size_t npix = (size_t)a.r.w * a.r.h;
+    const uint32_t B = a.r.bounces, R = a.r.rr_start, b = a.depth;
+    const bool fast = a.r.fast_materials != 0;
+    const uint32_t owned = owned_tiles(a.r.n_tiles, a.r.tile_rank, a.r.tile_world);
+    const uint32_t pixel_wgs = owned * kBlocksPerTile;  // 256-pixel groups of the owned tiles
+    uint32_t count;
+    if constexpr (FIRST) {
+        count = pixel_wgs * 256u * a.batch_n;
+    } else {
+        count = *a.qin.count < a.qin.cap ? *a.qin.count : a.qin.cap;
+    }
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // every thread of the grid runs the same number of rounds (append_path has barriers and ballots)
+    const uint32_t rounds = (count + stride - 1) / stride;
+    for (uint32_t k = 0; k < rounds; ++k) {
+        const uint32_t i = k * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool have = i < count;
+        PathRec p;
+        bool survives = false;
+        if constexpr (FIRST) {
+            if (have) {
+                const uint32_t group = i / 256u;  // (sample, 256-pixel group): consecutive threads = one 16x16 block
+                p.smp = group / pixel_wgs;
+                uint32_t x, y;
+                have = lane_pixel(group % pixel_wgs, a.r.tiles_x, a.r.tile_rank, a.r.tile_world, a.r.w, a.r.h, x, y);
+                if (have) {
+                    p.pix = y * a.r.w + x;
+                    const float4 pp = a.prim_pos[p.pix], pn = a.prim_nrm[p.pix];
+                    p.idx = __builtin_bit_cast(int, pp.w);
+                    p.pos = mk3(pp.x, pp.y, pp.z);
+                    p.nrm = mk3(pn.x, pn.y, pn.z);
+                    p.contrib = mk3(1.0f, 1.0f, 1.0f);
+                    p.light = mk3(0.0f, 0.0f, 0.0f);
+                    if (p.idx < 0) {  // primary ray missed: the sample is the sky value stored in the record
+                        a.values[(size_t)p.smp * npix + p.pix] = make_float4(pp.x, pp.y, pp.z, 0.0f);
+                        have = false;
+                    }
+                }
+            }
+        } else {
+            if (have) p = load_path(a.qin, i);
+        }
+        if (have) {
+            const uint32_t skey = sample_key(a.r.seed_hi, pixel_key(a.r.seed_lo, p.pix), a.r.sample_base + a.batch_first + p.smp);
+            // shade the hit of bounce b (integrator.rs:50-81)
+            const float4 m_brdf = a.r.shade[2 * p.idx];
+            const float4 m_emit = a.r.shade[2 * p.idx + 1];
+            p.light = p.light + mk3(m_emit.x, m_emit.y, m_emit.z) * p.contrib;
+            const float r1 = draw(skey, 3 * b);
+            const float r2 = draw(skey, 3 * b + 1);
+            const f3 wi = sample_hemisphere(p.nrm, r1, r2);
+            const float cos_theta = __builtin_fmaxf(dot(wi, p.nrm), 0.0f);
+            p.contrib = p.contrib * scatter_weight(mk3(m_brdf.x, m_brdf.y, m_brdf.z), cos_theta, fast);
+            bool done = false;
+            if (b >= R) {
+                const float pr = __builtin_fmaxf(p.contrib.x, __builtin_fmaxf(p.contrib.y, p.contrib.z));
+                if (draw(skey, 3 * b + 2) > pr) {
+                    done = true;
+                } else {
+                    p.contrib = roulette_divide(p.contrib, pr, fast);
+                }
+            }
+            if (!done && b + 1 < B) {
+                const f3 o = p.pos + p.nrm * kEps;
+                const HitRec h = wf_trace<ACCEL>(a, s_dyn, o, wi);
+                if (h.idx >= 0) {
+                    hit_geometry(wf_sphere<ACCEL>(a, s_dyn, h.idx), o, wi, h.t, p.pos, p.nrm);
+                    p.idx = h.idx;
+                    survives = true;
+                } else {
+                    p.light = p.light + sky_eval(a.r, wi) * p.contrib;
+                }
+            }
+            // roulette / bounce budget end the path without a sky term (integrator.rs:47,74,92)
+            if (!survives) a.values[(size_t)p.smp * npix + p.pix] = make_float4(p.light.x, p.light.y, p.light.z, 0.0f);
+        }
+        append_path(a.qout, survives, p, s_cnt);
+    }
+}
+
+// bounces == 0: the bounce loop never runs, every sample is (0,0,0) (integrator.rs:47,92)
+__global__ __launch_bounds__(256) void wf_zero_values(const WfArgs a) {
+    uint32_t x, y;
+    if (!lane_pixel(blockIdx.x, a.r.tiles_x, a.r.tile_rank, a.r.tile_world, a.r.w, a.r.h, x, y)) return;
+    const size_t npix = (size_t)a.r.w * a.r.h;
+    for (uint32_t j = 0; j < a.batch_n; ++j) a.values[(size_t)j * npix + y * a.r.w + x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void wf_commit(const WfArgs a) {
+    uint32_t x, y;
+    if (!lane_pixel(blockIdx.x, a.r.tiles_x, a.r.tile_rank, a.r.tile_world, a.r.w, a.r.h, x, y)) return;
+    const uint32_t pixel = y * a.r.w + x;
+    const size_t npix = (size_t)a.r.w * a.r.h;
+    float4 t = a.first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : a.tileacc[pixel];
+    for (uint32_t j = 0; j < a.batch_n; ++j) {
+        const float4 v = a.values[(size_t)j * npix + pixel];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += 1.0f;
+    }
+    if (a.last_batch) {  // Accumulator::merge_tile: framebuffer += tile, sample_counts += samples of the block
+        float4 f = a.r.sum[pixel];
+        f.x += t.x; f.y += t.y; f.z += t.z; f.w += t.w;
+        a.r.sum[pixel] = f;
+        a.r.counts[pixel] += a.block_spp;
+    } else {
+        a.tileacc[pixel] = t;
+    }
+}
+
+}  // namespace
+
+hipError_t init_wavefront_kernels() {
+    const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
+    hipError_t e = hipFuncSetAttribute((const void*)wf_primary<kAccelLinear>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)wf_bounce<kAccelLinear, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)wf_bounce<kAccelLinear, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+}
+
+// Renders a.r.spp samples per owned pixel (sample indices a.r.sample_base ...) into a.r.sum / a.r.counts.
+// `bounce_wgs` = workgroups of a bounce stage (a few per CU).
+hipError_t launch_wavefront(const WfArgs& a_in, int accel, uint32_t bounce_wgs, hipStream_t stream) {
+    WfArgs a = a_in;
+    const uint32_t owned = owned_tiles(a.r.n_tiles, a.r.tile_rank, a.r.tile_world);
+    if (owned == 0 || a.r.spp == 0) return hipSuccess;
+    const dim3 block(256), pix_grid(owned * kBlocksPerTile);
+    const size_t owned_pixels = (size_t)owned * kTile * kTile;
+    const uint32_t per_batch = (uint32_t)(a.qin.cap / owned_pixels);
+    if (per_batch == 0) return hipErrorInvalidValue;  // the host sizes the queues for at least one sample per pixel
+    const size_t lds = accel == kAccelLbvh ? (size_t)a.r.bvh.stack_depth * 256 * sizeof(int) : (size_t)a.r.n_spheres * sizeof(float4);
+    hipError_t e;
+
+    if (accel == kAccelLbvh) {
+        hipLaunchKernelGGL(wf_primary<kAccelLbvh>, pix_grid, block, lds, stream, a);
+    } else {
+        hipLaunchKernelGGL(wf_primary<kAccelLinear>, pix_grid, block, lds, stream, a);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+
+    const uint32_t total = a.r.spp, sb = a.r.sample_block, base0 = a.r.sample_base;
+    for (uint32_t blk_first = 0; blk_first < total; blk_first += sb) {
+        const uint32_t blk_n = total - blk_first < sb ? total - blk_first : sb;
+        a.block_spp = blk_n;
+        for (uint32_t done = 0; done < blk_n; done += per_batch) {
+            a.batch_n = blk_n - done < per_batch ? blk_n - done : per_batch;
+            a.batch_first = blk_first + done;
+            a.first_batch = done == 0;
+            a.last_batch = done + a.batch_n >= blk_n;
+            a.r.sample_base = base0;
+            WfQueue q0 = a_in.qin, q1 = a_in.qout;
+            if (a.r.bounces == 0) {
+                hipLaunchKernelGGL(wf_zero_values, pix_grid, block, 0, stream, a);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
+            for (uint32_t d = 0; d < a.r.bounces; ++d) {
+                a.depth = d;
+                a.qin = q0;
+                a.qout = q1;
+                if ((e = hipMemsetAsync(q1.count, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+                if (accel == kAccelLbvh) {
+                    if (d == 0) {
+                        hipLaunchKernelGGL((wf_bounce<kAccelLbvh, true>), dim3(bounce_wgs), block, lds, stream, a);
+                    } else {
+                        hipLaunchKernelGGL((wf_bounce<kAccelLbvh, false>), dim3(bounce_wgs), block, lds, stream, a);
+                    }
+                } else {
+                    if (d == 0) {
+                        hipLaunchKernelGGL((wf_bounce<kAccelLinear, true>), dim3(bounce_wgs), block, lds, stream, a);
+                    } else {
+                        hipLaunchKernelGGL((wf_bounce<kAccelLinear, false>), dim3(bounce_wgs), block, lds, stream, a);
+                    }
+                }
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                WfQueue t = q0;
+                q0 = q1;
+                q1 = t;
+            }
+            hipLaunchKernelGGL(wf_commit, pix_grid, block, 0, stream, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+}  // namespace pt

@@ -91,6 +91,10 @@ class RayTracer:
         if seed is not None:
             self.seed = int(seed)
 
+    def set_schedule(self, schedule, max_paths=0):
+        """IR_SCHEDULE_AUTO / REGENERATION (one kernel, paths in registers) / WAVEFRONT (kernel per stage, HBM queues)."""
+        _capi.check(self._ctx, _capi.lib.ir_set_schedule(self._ctx, int(schedule), int(max_paths)))
+
     def set_sample_block(self, samples_per_block):
         """Samples per accumulation block of a multi-sample render call (ir_set_sample_block; default 128)."""
         _capi.check(self._ctx, _capi.lib.ir_set_sample_block(self._ctx, int(samples_per_block)))

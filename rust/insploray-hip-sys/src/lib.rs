@@ -34,6 +34,7 @@ extern "C" {
     pub fn ir_pinhole_get_ray(local_to_world: *const c_float, position: *const c_float, fov: c_float, aspect_ratio: c_float,
                               width: u32, height: u32, x: u32, y: u32, out6: *mut c_float) -> c_int;
     pub fn ir_set_integrator(ctx: *mut ir_context, bounces: u32, max_compulsory_bounces: u32, seed: u64) -> c_int;
+    pub fn ir_set_schedule(ctx: *mut ir_context, schedule: c_int, max_paths: u32) -> c_int;
     pub fn ir_set_sample_block(ctx: *mut ir_context, samples_per_block: u32) -> c_int;
     pub fn ir_set_partition(ctx: *mut ir_context, mode: c_int, rank: u32, world: u32) -> c_int;
     pub fn ir_render(ctx: *mut ir_context, width: u32, height: u32, spp: u32, accumulate: c_int) -> c_int;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Minimal driver for rocprofv3 passes: renders one configuration a few times through the C ABI (no torch).
-usage: prof_driver.py [c1|c2|c3] [reps] [spp] [sample_block]"""
+usage: prof_driver.py [c1|c2|c3] [reps] [spp] [sample_block] [regen|wavefront] [max_paths]"""
 import os
 import sys
 
@@ -24,6 +24,10 @@ rt.set_active_camera(cam)
 rt.set_integrator(bounces=8, max_compulsory_bounces=2, seed=W.RNG_SEED)
 if len(sys.argv) > 4:
     rt.set_sample_block(int(sys.argv[4]))
+if len(sys.argv) > 5:
+    from path_tracer_amd import _capi
+    rt.set_schedule({"regen": _capi.IR_SCHEDULE_REGENERATION, "wavefront": _capi.IR_SCHEDULE_WAVEFRONT}[sys.argv[5]],
+                    int(sys.argv[6]) if len(sys.argv) > 6 else 0)
 for _ in range(reps):
     rt.render(scene, w, h, False, spp=spp)
     ms, n = rt.last_kernel_ms()
