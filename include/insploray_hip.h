@@ -132,7 +132,7 @@ int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);
  *   IR_SCHEDULE_WAVEFRONT    : one kernel per stage (primary, generate, one per bounce, commit); paths stream
  *                              through queues in device memory and are compacted between bounces with a wave64
  *                              ballot/prefix count; max_paths bounds the queue memory (60 B per path and queue,
- *                              16 B per path for the per-sample values; 0 keeps the default of 32 Mi paths);
+ *                              16 B per path for the per-sample values; 0 keeps the default of 128 Mi paths = ~22 GB);
  *   IR_SCHEDULE_AUTO         : the faster one for the scene as measured on MI355X.
  * Renders that collect statistics (ir_enable_stats) always use REGENERATION. */
 int ir_set_schedule(ir_context* ctx, int schedule, uint32_t max_paths);

@@ -70,7 +70,8 @@ struct ir_context {
     DeviceBuf d_partials;
     // wavefront schedule: path queues and per-sample values (allocated on first use)
     int schedule = IR_SCHEDULE_AUTO;
-    uint32_t wf_max_paths = 32u << 20;
+    bool wf_check_overflow = false;
+    uint32_t wf_max_paths = 128u << 20;
     DeviceBuf d_wf_queue[2], d_wf_counts, d_wf_values, d_wf_prim, d_wf_tileacc;
     uint64_t seed = 0x0123456789ABCDEFull;
 
@@ -542,26 +543,28 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
         const size_t owned_pixels = (size_t)owned * pt::kTile * pt::kTile;
         size_t cap = ctx->wf_max_paths;
         if (cap < owned_pixels) cap = owned_pixels;
-        if (cap > 0xfffffff0u) return fail(ctx, IR_ELIMIT, "ir_render: wavefront queue capacity overflow");
         size_t per_batch = owned_pixels ? cap / owned_pixels : 1;
         if (per_batch > ctx->sample_block) per_batch = ctx->sample_block;
         if (per_batch > spp) per_batch = spp;
         pt::WfArgs wa;
         memset(&wa, 0, sizeof(wa));
-        for (int k = 0; k < 2; ++k) IR_TRY(ensure(ctx, ctx->d_wf_queue[k], cap * (3 + 12) * sizeof(uint32_t)));
-        IR_TRY(ensure(ctx, ctx->d_wf_counts, 2 * sizeof(uint32_t)));
+        const uint32_t bounce_wgs = 256 * 8;
+        const size_t slots = pt::wavefront_queue_slots(per_batch * owned_pixels, bounce_wgs);
+        if (slots > 0xfffffff0u) return fail(ctx, IR_ELIMIT, "ir_render: wavefront queue capacity overflow");
+        for (int k = 0; k < 2; ++k) IR_TRY(ensure(ctx, ctx->d_wf_queue[k], slots * (3 + 12) * sizeof(uint32_t)));
+        IR_TRY(ensure(ctx, ctx->d_wf_counts, 4 * sizeof(uint32_t)));
         IR_TRY(ensure(ctx, ctx->d_wf_values, per_batch * n * sizeof(float4)));
         IR_TRY(ensure(ctx, ctx->d_wf_prim, 2 * n * sizeof(float4)));
         IR_TRY(ensure(ctx, ctx->d_wf_tileacc, n * sizeof(float4)));
         auto queue = [&](int k) {
             pt::WfQueue q;
-            uint32_t* base = (uint32_t*)ctx->d_wf_queue[k].p;
-            q.pix = base;
-            q.smp = base + cap;
-            q.idx = (int32_t*)(base + 2 * cap);
-            q.f = (float*)(base + 3 * cap);
+            uint32_t* qb = (uint32_t*)ctx->d_wf_queue[k].p;
+            q.pix = qb;
+            q.smp = qb + slots;
+            q.idx = (int32_t*)(qb + 2 * slots);
+            q.f = (float*)(qb + 3 * slots);
             q.count = (uint32_t*)ctx->d_wf_counts.p + k;
-            q.cap = (uint32_t)cap;
+            q.cap = (uint32_t)slots;
             return q;
         };
         wa.r = a;
@@ -574,10 +577,12 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
         wa.tileacc = (float4*)ctx->d_wf_tileacc.p;
         wa.qin = queue(0);
         wa.qout = queue(1);
-        // launch_wavefront batches by qin.cap / owned pixels: make that equal to per_batch
-        wa.qin.cap = wa.qout.cap = (uint32_t)(per_batch * owned_pixels);
+        wa.in_cursor = (uint32_t*)ctx->d_wf_counts.p + 2;
+        wa.overflow = (uint32_t*)ctx->d_wf_counts.p + 3;
+        IR_HIP(ctx, hipMemsetAsync(wa.overflow, 0, sizeof(uint32_t), ctx->stream));
+        ctx->wf_check_overflow = true;
         IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        IR_HIP(ctx, pt::launch_wavefront(wa, accel, 256 * 8, ctx->stream));
+        IR_HIP(ctx, pt::launch_wavefront(wa, accel, (uint32_t)per_batch, bounce_wgs, ctx->stream));
         IR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         ctx->events_recorded = true;
         ctx->last_launches = 1;
@@ -619,6 +624,12 @@ int ir_synchronize(ir_context* ctx) {
     if (!ctx) return IR_EINVAL;
     IR_TRY(use_device(ctx));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->wf_check_overflow) {
+        ctx->wf_check_overflow = false;
+        uint32_t flag = 0;
+        IR_HIP(ctx, hipMemcpy(&flag, (uint32_t*)ctx->d_wf_counts.p + 3, sizeof(flag), hipMemcpyDeviceToHost));
+        if (flag) return fail(ctx, IR_EDEVICE, "wavefront path queue overflowed: the frame is incomplete (internal sizing error)");
+    }
     return IR_OK;
 }
 

@@ -113,12 +113,15 @@ struct WfArgs {
     float4* values;      // [sample of the batch][pixel]: radiance of each finished sample
     float4* tileacc;     // [pixel]: running sum of the current sample block
     WfQueue qin, qout;
+    uint32_t* in_cursor;            // next unclaimed input entry (persistent LBVH bounce stage)
+    uint32_t* overflow;             // set if a queue ever overflowed (sized so that it cannot)
     uint32_t batch_first, batch_n;  // samples [batch_first, batch_first + batch_n) of the call
     uint32_t block_spp;             // samples of the current block
     uint32_t first_batch, last_batch, depth;
 };
 hipError_t init_wavefront_kernels();
-hipError_t launch_wavefront(const WfArgs& a, int accel, uint32_t bounce_wgs, hipStream_t stream);
+size_t wavefront_queue_slots(size_t paths, uint32_t bounce_wgs);
+hipError_t launch_wavefront(const WfArgs& a, int accel, uint32_t per_batch, uint32_t bounce_wgs, hipStream_t stream);
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 enum { kAccelLinear = 0, kAccelLbvh = 1 };

@@ -60,7 +60,7 @@ __device__ __forceinline__ void append_path(const WfQueue& q, bool live, const P
     wave_base = (uint32_t)__builtin_amdgcn_readlane((int)wave_base, (int)__builtin_ctzll(mask));
     if (!live) return;
     const uint32_t i = s_cnt[1] + wave_base + rank;
-    if (i >= q.cap) return;
+    if (i >= q.cap) return;  // cannot happen: a stage never emits more paths than it reads
     q.pix[i] = p.pix;
     q.smp[i] = p.smp;
     q.idx[i] = p.idx;
@@ -205,6 +205,203 @@ __global__ __launch_bounds__(256) void wf_bounce(const WfArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Bounce stage for the LBVH: persistent waves with dynamic path fetch.  Ray lengths vary wildly, so a lane that has
+// finished its path takes the next one instead of waiting for the wave (paths are independent here: nothing ties a
+// lane to a pixel).  A wave owns a chunk of kWfChunk consecutive input entries and a chunk of output slots at a time
+// (one global atomic per chunk); inside a chunk, lanes are served with ballot + mbcnt.  Unused output slots of a
+// chunk are marked empty (idx = -1) and skipped by the next stage.  Lane states as in render_lbvh_kernel: at an inner
+// node, at a leaf, or waiting for the shading block (finish a landed ray / shade a fresh path).
+// ----------------------------------------------------------------------------------------------------
+constexpr uint32_t kWfChunk = 256;
+
+__device__ __forceinline__ void store_path(const WfQueue& q, uint32_t i, const PathRec& p) {
+    q.pix[i] = p.pix;
+    q.smp[i] = p.smp;
+    q.idx[i] = p.idx;
+    const size_t c = q.cap;
+    q.f[i] = p.pos.x; q.f[c + i] = p.pos.y; q.f[2 * c + i] = p.pos.z;
+    q.f[3 * c + i] = p.nrm.x; q.f[4 * c + i] = p.nrm.y; q.f[5 * c + i] = p.nrm.z;
+    q.f[6 * c + i] = p.contrib.x; q.f[7 * c + i] = p.contrib.y; q.f[8 * c + i] = p.contrib.z;
+    q.f[9 * c + i] = p.light.x; q.f[10 * c + i] = p.light.y; q.f[11 * c + i] = p.light.z;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256, 6) void wf_bounce_tree(const WfArgs a) {
+    extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
+    int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t npix = (size_t)a.r.w * a.r.h;
+    const uint32_t B = a.r.bounces, R = a.r.rr_start, b = a.depth;
+    const bool fast = a.r.fast_materials != 0;
+    const uint32_t pixel_wgs = owned_tiles(a.r.n_tiles, a.r.tile_rank, a.r.tile_world) * kBlocksPerTile;
+    uint32_t count;
+    if constexpr (FIRST) {
+        count = pixel_wgs * 256u * a.batch_n;
+    } else {
+        count = *a.qin.count < a.qin.cap ? *a.qin.count : a.qin.cap;
+    }
+    // wave-uniform cursors
+    uint32_t in_next = 0, in_end = 0, out_next = 0, out_end = 0;
+    bool input_done = false;
+
+    PathRec p;
+    p.pix = p.smp = 0; p.idx = -1;
+    p.pos = p.nrm = p.contrib = p.light = mk3(0, 0, 0);
+    LbvhCursor cur;
+    cursor_begin(cur, mk3(0, 0, 0), mk3(0, 0, 1));
+    cur.cur = kCursorDone;
+    bool busy = false;        // the lane holds a path
+    bool fresh = false;       // ... that has not been shaded yet
+    bool traversing = false;  // ... whose bounce ray is still in the tree
+
+    for (;;) {
+        // ---- hand input entries to the idle lanes
+        while (!input_done) {
+            const unsigned long long need = __builtin_amdgcn_ballot_w64(!busy);
+            if (need == 0ull) break;
+            if (in_next == in_end) {  // next chunk
+                uint32_t start = 0;
+                if (lane == 0) start = atomicAdd(a.in_cursor, kWfChunk);
+                start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+                if (start >= count) {
+                    input_done = true;
+                    break;
+                }
+                in_next = start;
+                in_end = start + kWfChunk < count ? start + kWfChunk : count;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t avail = in_end - in_next, wanted = (uint32_t)__builtin_popcountll(need);
+            if (!busy && rank < avail) {
+                const uint32_t i = in_next + rank;
+                bool ok;
+                if constexpr (FIRST) {
+                    const uint32_t group = i / 256u;
+                    p.smp = group / pixel_wgs;
+                    uint32_t x, y;
+                    // lane_pixel uses threadIdx.x for the position inside the 16x16 block: entry i % 256 plays that part
+                    const uint32_t t = i & 255u, wave = t >> 6, ln = t & 63u;
+                    const uint32_t k = (group % pixel_wgs) / kBlocksPerTile, sub = (group % pixel_wgs) % kBlocksPerTile;
+                    const uint32_t tile = a.r.tile_rank + k * a.r.tile_world;
+                    x = (tile % a.r.tiles_x) * kTile + (sub & 3) * kBlockEdge + (wave & 1) * 8 + (ln & 7);
+                    y = (tile / a.r.tiles_x) * kTile + (sub >> 2) * kBlockEdge + (wave >> 1) * 8 + (ln >> 3);
+                    ok = x < a.r.w && y < a.r.h;
+                    if (ok) {
+                        p.pix = y * a.r.w + x;
+                        const float4 pp = a.prim_pos[p.pix], pn = a.prim_nrm[p.pix];
+                        p.idx = __builtin_bit_cast(int, pp.w);
+                        p.pos = mk3(pp.x, pp.y, pp.z);
+                        p.nrm = mk3(pn.x, pn.y, pn.z);
+                        p.contrib = mk3(1.0f, 1.0f, 1.0f);
+                        p.light = mk3(0.0f, 0.0f, 0.0f);
+                        if (p.idx < 0) {  // primary ray missed: the sample is the sky value stored in the record
+                            a.values[(size_t)p.smp * npix + p.pix] = make_float4(pp.x, pp.y, pp.z, 0.0f);
+                            ok = false;
+                        }
+                    }
+                } else {
+                    p = load_path(a.qin, i);
+                    ok = p.idx >= 0;  // empty slot of a partly filled chunk
+                }
+                busy = ok;
+                fresh = ok;
+            }
+            in_next += wanted < avail ? wanted : avail;
+        }
+        const bool waiting = busy && !traversing;  // fresh path to shade, or landed ray to finish
+        const bool at_inner = traversing && cur.cur >= 0, at_leaf = traversing && cur.cur < 0;
+        const uint32_t n_wait = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(waiting));
+        const uint32_t n_inner = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(at_inner));
+        const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(at_leaf));
+        if (n_wait + n_inner + n_leaf == 0) {
+            if (input_done) break;
+            continue;
+        }
+        if (n_wait >= 32u || n_inner + n_leaf == 0) {
+            bool survives = false;
+            if (waiting) {
+                if (!fresh) {  // the bounce ray has landed (integrator.rs:50-51, 82-90)
+                    if (cur.idx >= 0) {
+                        hit_geometry(a.r.spheres[cur.idx], cur.o, cur.d, cur.best, p.pos, p.nrm);
+                        p.idx = cur.idx;
+                        survives = true;
+                    } else {
+                        p.light = p.light + sky_eval(a.r, cur.d) * p.contrib;
+                        a.values[(size_t)p.smp * npix + p.pix] = make_float4(p.light.x, p.light.y, p.light.z, 0.0f);
+                    }
+                    busy = false;
+                } else {  // shade the hit of bounce b (integrator.rs:50-81)
+                    fresh = false;
+                    const uint32_t skey = sample_key(a.r.seed_hi, pixel_key(a.r.seed_lo, p.pix), a.r.sample_base + a.batch_first + p.smp);
+                    const float4 m_brdf = a.r.shade[2 * p.idx];
+                    const float4 m_emit = a.r.shade[2 * p.idx + 1];
+                    p.light = p.light + mk3(m_emit.x, m_emit.y, m_emit.z) * p.contrib;
+                    const float r1 = draw(skey, 3 * b);
+                    const float r2 = draw(skey, 3 * b + 1);
+                    const f3 wi = sample_hemisphere(p.nrm, r1, r2);
+                    const float cos_theta = __builtin_fmaxf(dot(wi, p.nrm), 0.0f);
+                    p.contrib = p.contrib * scatter_weight(mk3(m_brdf.x, m_brdf.y, m_brdf.z), cos_theta, fast);
+                    bool done = false;
+                    if (b >= R) {
+                        const float pr = __builtin_fmaxf(p.contrib.x, __builtin_fmaxf(p.contrib.y, p.contrib.z));
+                        if (draw(skey, 3 * b + 2) > pr) {
+                            done = true;
+                        } else {
+                            p.contrib = roulette_divide(p.contrib, pr, fast);
+                        }
+                    }
+                    if (!done && b + 1 < B) {
+                        cursor_begin(cur, p.pos + p.nrm * kEps, wi);
+                        traversing = true;
+                    } else {  // roulette / bounce budget: no sky term (integrator.rs:47,74,92)
+                        a.values[(size_t)p.smp * npix + p.pix] = make_float4(p.light.x, p.light.y, p.light.z, 0.0f);
+                        busy = false;
+                    }
+                }
+            }
+            // ---- compacted append of the survivors (whole wave takes part)
+            const unsigned long long smask = __builtin_amdgcn_ballot_w64(survives);
+            if (smask != 0ull) {
+                const uint32_t n = (uint32_t)__builtin_popcountll(smask);
+                if (out_end - out_next < n) {
+                    if (out_next + lane < out_end) a.qout.idx[out_next + lane] = -1;  // close the old chunk (< 64 slots left)
+                    uint32_t start = 0;
+                    if (lane == 0) start = atomicAdd(a.qout.count, kWfChunk);
+                    out_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+                    out_end = out_next + kWfChunk;
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u));
+                if (survives) {
+                    if (out_next + rank < a.qout.cap) {
+                        store_path(a.qout, out_next + rank, p);
+                    } else {
+                        atomicOr(a.overflow, 1u);  // cannot happen with queues sized by wavefront_queue_slots
+                    }
+                }
+                out_next += n;
+            }
+        } else if (n_inner >= n_leaf) {
+            for (uint32_t k = 0; k < 2; ++k) {
+                if (traversing && cur.cur >= 0) {
+                    uint32_t nv = 0;
+                    cursor_inner_step<false>(a.r.bvh, cur, stack, 256u, nv);
+                    if (cur.cur == kCursorDone) traversing = false;
+                }
+            }
+        } else {
+            if (at_leaf) {
+                uint32_t c0 = 0, c1 = 0;
+                cursor_leaf_step<false>(a.r.bvh, cur, stack, 256u, c0, c1);
+                if (cur.cur == kCursorDone) traversing = false;
+            }
+        }
+    }
+    // close the last output chunk
+    for (uint32_t i = out_next + lane; i < out_end; i += 64u)
+        if (i < a.qout.cap) a.qout.idx[i] = -1;
+}
+
 // bounces == 0: the bounce loop never runs, every sample is (0,0,0) (integrator.rs:47,92)
 __global__ __launch_bounds__(256) void wf_zero_values(const WfArgs a) {
     uint32_t x, y;
@@ -235,6 +432,12 @@ __global__ __launch_bounds__(256) void wf_commit(const WfArgs a) {
 
 }  // namespace
 
+// Queue slots that `paths` paths per batch can need: the persistent LBVH stage hands out output slots in chunks of
+// kWfChunk per wave and abandons fewer than 64 slots when it closes a chunk (<= 1/3 extra), plus one open chunk per wave.
+size_t wavefront_queue_slots(size_t paths, uint32_t bounce_wgs) {
+    return paths + paths / 3 + (size_t)bounce_wgs * 4 * kWfChunk + kWfChunk;
+}
+
 hipError_t init_wavefront_kernels() {
     const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
     hipError_t e = hipFuncSetAttribute((const void*)wf_primary<kAccelLinear>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -246,14 +449,13 @@ hipError_t init_wavefront_kernels() {
 
 // Renders a.r.spp samples per owned pixel (sample indices a.r.sample_base ...) into a.r.sum / a.r.counts.
 // `bounce_wgs` = workgroups of a bounce stage (a few per CU).
-hipError_t launch_wavefront(const WfArgs& a_in, int accel, uint32_t bounce_wgs, hipStream_t stream) {
+hipError_t launch_wavefront(const WfArgs& a_in, int accel, uint32_t per_batch, uint32_t bounce_wgs, hipStream_t stream) {
     WfArgs a = a_in;
     const uint32_t owned = owned_tiles(a.r.n_tiles, a.r.tile_rank, a.r.tile_world);
     if (owned == 0 || a.r.spp == 0) return hipSuccess;
     const dim3 block(256), pix_grid(owned * kBlocksPerTile);
-    const size_t owned_pixels = (size_t)owned * kTile * kTile;
-    const uint32_t per_batch = (uint32_t)(a.qin.cap / owned_pixels);
-    if (per_batch == 0) return hipErrorInvalidValue;  // the host sizes the queues for at least one sample per pixel
+    if (per_batch == 0 || wavefront_queue_slots((size_t)owned * kTile * kTile * per_batch, bounce_wgs) > a.qin.cap)
+        return hipErrorInvalidValue;  // the host sizes the queues with wavefront_queue_slots
     const size_t lds = accel == kAccelLbvh ? (size_t)a.r.bvh.stack_depth * 256 * sizeof(int) : (size_t)a.r.n_spheres * sizeof(float4);
     hipError_t e;
 
@@ -285,10 +487,11 @@ hipError_t launch_wavefront(const WfArgs& a_in, int accel, uint32_t bounce_wgs, 
                 a.qout = q1;
                 if ((e = hipMemsetAsync(q1.count, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
                 if (accel == kAccelLbvh) {
+                    if ((e = hipMemsetAsync(a.in_cursor, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
                     if (d == 0) {
-                        hipLaunchKernelGGL((wf_bounce<kAccelLbvh, true>), dim3(bounce_wgs), block, lds, stream, a);
+                        hipLaunchKernelGGL((wf_bounce_tree<true>), dim3(bounce_wgs), block, lds, stream, a);
                     } else {
-                        hipLaunchKernelGGL((wf_bounce<kAccelLbvh, false>), dim3(bounce_wgs), block, lds, stream, a);
+                        hipLaunchKernelGGL((wf_bounce_tree<false>), dim3(bounce_wgs), block, lds, stream, a);
                     }
                 } else {
                     if (d == 0) {
