@@ -126,3 +126,22 @@ def test_lbvh_radiance_on_mid_sized_scene(pta, tracer, oracle):
     scene = W.scene_s2(n=200)
     _compare(pta, tracer, oracle, scene, W.camera_s2(128, 72), 128, 72, 20, bounces=8)
     assert tracer.get_accel_info()["accel"] == _capi.IR_ACCEL_LBVH
+
+
+def test_limits_are_errors_not_crashes(pta, tracer):
+    from path_tracer_amd import _capi, workloads as W
+    scene = W.scene_s1(skybox=None)
+    tracer.set_active_camera(W.default_camera(70000, 70000))
+    with pytest.raises(pta.InsplorayError) as e:
+        tracer.render(scene, 70000, 70000, False)            # 4.9 G pixels: refused before anything is allocated
+    assert e.value.code == _capi.IR_ELIMIT
+    with pytest.raises(pta.InsplorayError):
+        tracer.set_sample_block(0)
+    with pytest.raises(pta.InsplorayError):
+        tracer.set_schedule(7)
+    with pytest.raises(pta.InsplorayError):
+        tracer.set_sky_filter(5)
+    # the context is still usable afterwards
+    tracer.set_active_camera(W.default_camera(32, 18))
+    tracer.render(scene, 32, 18, False, spp=2)
+    assert (tracer.get_radiance()[1] == 2).all()
