@@ -9,7 +9,8 @@
 //   chunks = [part] y size data (scanline) or [part] tx ty lx ly size data (tile), channel-planar lines,
 //   ZIP/ZIPS = zlib deflate over (byte de-interleave + delta predictor), RLE = the same filter + byte runs.
 // Supported: single- and multi-part files, scanline and tiled (level 0) parts, HALF / FLOAT / UINT samples,
-// compression NONE, RLE, ZIPS, ZIP.  PIZ, PXR24, B44(A) and DWAA/DWAB are reported as unsupported.
+// compression NONE, RLE, ZIPS, ZIP, PIZ and PXR24 (the last two in exr_codecs.cpp).  The lossy B44(A) and
+// DWAA/DWAB are reported as unsupported.
 #include <zlib.h>
 
 #include <cmath>
@@ -21,6 +22,7 @@
 #include <vector>
 
 #include "../../include/insploray_hip.h"
+#include "exr_codecs.h"
 
 namespace {
 
@@ -321,7 +323,7 @@ int set_err(int code, const std::string& msg) {
 
 // decode one chunk's pixel bytes into `raw` (uncompressed size `expect`)
 bool decode_block(int compression, const uint8_t* data, size_t size, size_t expect, std::vector<uint8_t>& raw,
-                  std::vector<uint8_t>& scratch) {
+                  std::vector<uint8_t>& scratch, const std::vector<int>& types, int bw, int bh) {
     if (compression == 0 || size == expect) {  // NONE, or stored raw because compression did not help
         if (size != expect) return false;
         raw.assign(data, data + size);
@@ -339,6 +341,8 @@ bool decode_block(int compression, const uint8_t* data, size_t size, size_t expe
         unfilter(raw, scratch);
         return true;
     }
+    if (compression == 4) return exr::piz_decode(data, size, types, bw, bh, raw) && raw.size() == expect;
+    if (compression == 5) return exr::pxr24_decode(data, size, types, bw, bh, raw) && raw.size() == expect;
     return false;
 }
 
@@ -411,7 +415,7 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
         }
     if (sel == parts.size()) return set_err(IR_EIO, "EXR file has no layer with R, G and B channels");
     const Part& p = parts[sel];
-    if (p.compression > 3) {
+    if (p.compression > 5) {
         static const char* names[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
         return set_err(IR_EIO, std::string("EXR compression ") + (p.compression < 10 ? names[p.compression] : "?") + " is not supported");
     }
@@ -428,6 +432,8 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
     if (!img) return set_err(IR_ENOMEM, "out of memory for the EXR image");
     std::memset(img, 0, (size_t)W * H * 3 * sizeof(float));
     std::vector<uint8_t> raw, scratch;
+    std::vector<int> types;
+    for (const Channel& c : p.channels) types.push_back(c.type);
     const int lpb = p.tiled ? 0 : lines_per_block(p.compression);
 
     auto bail = [&](const char* m) {
@@ -463,7 +469,7 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
         const int32_t size = c.i32();
         if (!c.ok || size < 0 || !c.need((size_t)size)) return bail("truncated EXR chunk");
         const size_t expect = (size_t)bw * bh * bytes_per_pixel;
-        if (!decode_block(p.compression, bytes + c.pos, (size_t)size, expect, raw, scratch)) return bail("corrupt EXR chunk data");
+        if (!decode_block(p.compression, bytes + c.pos, (size_t)size, expect, raw, scratch, types, bw, bh)) return bail("corrupt EXR chunk data");
         // lines are channel-planar: for each line, for each channel (file order), bw samples
         for (int ly = 0; ly < bh; ++ly) {
             const uint8_t* line = raw.data() + (size_t)ly * bw * bytes_per_pixel;
@@ -518,7 +524,8 @@ int ir_exr_load(const char* path, float** out_rgb, uint32_t* out_w, uint32_t* ou
 
 int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int compression, int pixel_type) {
     if (!path || !rgb || w == 0 || h == 0) return set_err(IR_EINVAL, "ir_exr_save: NULL or empty image");
-    if (compression < 0 || compression > 3) return set_err(IR_EINVAL, "ir_exr_save: compression must be 0 (NONE), 1 (RLE), 2 (ZIPS) or 3 (ZIP)");
+    if (compression < 0 || compression > 5)
+        return set_err(IR_EINVAL, "ir_exr_save: compression must be 0 (NONE), 1 (RLE), 2 (ZIPS), 3 (ZIP), 4 (PIZ) or 5 (PXR24)");
     if (pixel_type != 1 && pixel_type != 2) return set_err(IR_EINVAL, "ir_exr_save: pixel_type must be 1 (HALF) or 2 (FLOAT)");
     std::vector<uint8_t> o;
     put_i32(o, 20000630);
@@ -585,6 +592,15 @@ int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int 
         if (compression == 1) {
             filter(raw.data(), raw.size(), filt);
             rle_encode(filt, comp);
+            if (comp.size() < raw.size()) {
+                payload = comp.data();
+                payload_n = comp.size();
+            }
+        } else if (compression >= 4) {
+            const std::vector<int> types(3, pixel_type);
+            const bool ok = compression == 4 ? exr::piz_encode(raw.data(), types, (int)w, (int)bh, comp)
+                                             : exr::pxr24_encode(raw.data(), types, (int)w, (int)bh, comp);
+            if (!ok) return set_err(IR_EIO, "EXR block encoder failed");
             if (comp.size() < raw.size()) {
                 payload = comp.data();
                 payload_n = comp.size();

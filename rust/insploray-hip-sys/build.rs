@@ -13,14 +13,14 @@ fn main() {
         // no FMA contraction: results stay bit-comparable with the CPU restatement of the reference
         .args(["-ffp-contract=off", "-fno-fast-math"])
         .arg("-o").arg(&lib)
-        .args(["insploray_hip.hip", "pt_kernels.hip", "pt_wavefront.hip", "pt_selftest.hip", "host_math.cpp", "exr_io.cpp", "lbvh.cpp"].map(|f| csrc.join(f)))
+        .args(["insploray_hip.hip", "pt_kernels.hip", "pt_wavefront.hip", "pt_selftest.hip", "host_math.cpp", "exr_io.cpp", "exr_codecs.cpp", "lbvh.cpp"].map(|f| csrc.join(f)))
         .arg("-lz")
         .status()
         .expect("hipcc not found (set HIPCC)");
     assert!(status.success(), "hipcc failed");
     println!("cargo:rustc-link-search=native={}", out.display());
     println!("cargo:rustc-link-lib=dylib=insploray_hip");
-    for f in ["insploray_hip.hip", "pt_kernels.hip", "pt_wavefront.hip", "pt_selftest.hip", "pt_kernels.h", "pt_device.h", "lbvh.h", "lbvh.cpp", "host_math.cpp", "exr_io.cpp"] {
+    for f in ["insploray_hip.hip", "pt_kernels.hip", "pt_wavefront.hip", "pt_selftest.hip", "pt_kernels.h", "pt_device.h", "lbvh.h", "lbvh.cpp", "host_math.cpp", "exr_io.cpp", "exr_codecs.cpp", "exr_codecs.h"] {
         println!("cargo:rerun-if-changed={}", csrc.join(f).display());
     }
 }
