@@ -55,9 +55,9 @@ struct Builder {
         out->nodes.emplace_back();
         out->max_depth = std::max(out->max_depth, depth);
         BvhNode nd;
-        bounds(first, last, nd.lo, nd.hi);
         const uint32_t count = last - first;
         if (count <= kLeafMax) {
+            bounds(first, last, nd.lo, nd.hi);
             nd.leaf = (int32_t)(first * 8 + count);
         } else {
             nd.leaf = -1;
@@ -76,8 +76,12 @@ struct Builder {
                 split = lo_i;
                 --b;
             }
-            build(first, split, b, depth + 1);
-            build(split, last, b, depth + 1);
+            const uint32_t l = build(first, split, b, depth + 1);
+            const uint32_t r = build(split, last, b, depth + 1);
+            for (int k = 0; k < 3; ++k) {  // union of the children's boxes (min/max are exact)
+                nd.lo[k] = std::min(out->nodes[l].lo[k], out->nodes[r].lo[k]);
+                nd.hi[k] = std::max(out->nodes[l].hi[k], out->nodes[r].hi[k]);
+            }
         }
         nd.skip = (int32_t)out->nodes.size();
         out->nodes[me] = nd;
