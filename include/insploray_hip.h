@@ -42,6 +42,7 @@ enum {
 enum { IR_SKY_NEAREST = 0, IR_SKY_BILINEAR = 1 };  /* exr.rs:20-23 is NEAREST */
 enum { IR_PARTITION_NONE = 0, IR_PARTITION_TILES = 1, IR_PARTITION_SAMPLES = 2 };
 enum { IR_ACCEL_AUTO = 0, IR_ACCEL_LINEAR = 1, IR_ACCEL_LBVH = 2 };
+enum { IR_BUILD_AUTO = 0, IR_BUILD_HOST = 1, IR_BUILD_DEVICE = 2 };
 enum { IR_SCHEDULE_AUTO = 0, IR_SCHEDULE_REGENERATION = 1, IR_SCHEDULE_WAVEFRONT = 2 };
 
 /* ABI version of this header (bumped on incompatible change). */
@@ -89,6 +90,21 @@ int ir_set_accel(ir_context* ctx, int accel);
 /* What the next launch will use for the current scene: *out_accel = IR_ACCEL_LINEAR or IR_ACCEL_LBVH, LBVH node
  * count and depth (0 for the scan).  Builds the LBVH if it is selected and stale.  Any pointer may be NULL. */
 int ir_get_accel_info(ir_context* ctx, int* out_accel, uint32_t* out_nodes, uint32_t* out_depth);
+/* Where the LBVH is built when the scene changed (the reference's editor, app.rs:59-116, edits spheres between
+ * frames; the reference itself has nothing to rebuild).  IR_BUILD_HOST: Morton sort and top-down splits on the CPU,
+ * arrays uploaded.  IR_BUILD_DEVICE: the same tree built by kernels from the spheres already on the device (radix
+ * sort, Karras radix tree, bottom-up boxes), byte-identical arrays; a tree too deep for the traversal stack falls
+ * back to the host's median-split build.  IR_BUILD_AUTO (default): device from 2048 spheres. */
+int ir_set_accel_build(ir_context* ctx, int build);
+/* Builder that produced the current LBVH (IR_BUILD_HOST / IR_BUILD_DEVICE) and the wall time of that build in
+ * seconds, uploads and synchronisation included.  Builds the LBVH if it is selected and stale. */
+int ir_get_accel_build_info(ir_context* ctx, int* out_builder, double* out_seconds);
+/* Copies the LBVH arrays to the host (for inspection and tests): n_nodes x 64-byte wide nodes (layout in
+ * path_tracer_amd/csrc/lbvh.h), n_spheres x 4 floats (cx, cy, cz, r*r) and n_spheres original indices in leaf
+ * order.  n_nodes / n_spheres must equal ir_get_accel_info's node count / the scene's sphere count; any pointer
+ * may be NULL.  IR_ESTATE when the scene is rendered with the linear scan. */
+int ir_download_accel(ir_context* ctx, void* wide_nodes, uint32_t n_nodes, float* leaf_spheres, int32_t* leaf_index,
+                      uint32_t n_spheres);
 
 /* -------------------------------------------------------------------------------------------------
  * Camera.  `dyn Camera` (cameras/mod.rs:7-17) is host code; PinholeCamera is the fast path.

@@ -18,6 +18,7 @@
 
 #include "../../include/insploray_hip.h"
 #include "lbvh.h"
+#include "pt_lbvh_build.h"
 #include "pt_kernels.h"
 
 namespace {
@@ -46,10 +47,13 @@ struct ir_context {
     bool fast_materials = false;
     uint32_t n_spheres = 0;
     DeviceBuf d_spheres, d_shade;
-    // LBVH (built on the host at ir_set_spheres / ir_set_accel when the LBVH is the selected structure)
-    DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index;
+    // LBVH (built before the first launch that needs it, on the host or on the device: ir_set_accel_build)
+    DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index, d_bvh_scratch;
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_stack = 0;
     bool bvh_valid = false;
+    int bvh_build = IR_BUILD_AUTO;
+    int bvh_built_by = IR_BUILD_HOST;
+    double bvh_build_seconds = 0.0;
     float sky[3] = {0.0f, 0.0f, 0.0f};
     DeviceBuf d_skybox;
     uint32_t sky_w = 0, sky_h = 0;
@@ -212,8 +216,10 @@ int selected_accel(const ir_context* ctx) {
     return ctx->n_spheres >= kAutoLbvhFrom ? pt::kAccelLbvh : pt::kAccelLinear;
 }
 
-int ensure_bvh(ir_context* ctx) {
-    if (selected_accel(ctx) != pt::kAccelLbvh || ctx->bvh_valid) return IR_OK;
+// AUTO builds on the device from this many spheres (measured crossover with the host build, tools/lbvh_build_times.py)
+constexpr uint32_t kAutoDeviceBuildFrom = 2048;
+
+int build_bvh_host(ir_context* ctx) {
     pt::Lbvh t;
     pt::build_lbvh(ctx->h_spheres.data(), ctx->n_spheres, t);
     IR_TRY(upload(ctx, ctx->d_bvh_nodes, t.wide.data(), t.wide.size() * sizeof(pt::WideNode)));
@@ -222,6 +228,48 @@ int ensure_bvh(ir_context* ctx) {
     ctx->bvh_nodes = (uint32_t)t.wide.size();
     ctx->bvh_depth = t.max_depth;
     ctx->bvh_stack = t.stack_depth;
+    ctx->bvh_built_by = IR_BUILD_HOST;
+    return IR_OK;
+}
+
+// Same arrays as build_bvh_host, produced by pt_lbvh_build.hip from the spheres already resident on the device.
+// *too_deep: the radix tree needs more than kMaxStack stack entries (the host builder then falls back to median splits).
+int build_bvh_device(ir_context* ctx, bool* too_deep) {
+    const uint32_t n = ctx->n_spheres;
+    IR_TRY(ensure(ctx, ctx->d_bvh_scratch, pt::lbvh_build_scratch_bytes(n)));
+    IR_TRY(ensure(ctx, ctx->d_bvh_spheres, (size_t)n * 16));
+    IR_TRY(ensure(ctx, ctx->d_bvh_index, (size_t)n * 4));
+    IR_TRY(ensure(ctx, ctx->d_bvh_nodes, (size_t)(n - 1) * sizeof(pt::WideNode)));
+    pt::LbvhDeviceTree tree;
+    const hipError_t e = pt::lbvh_build_device((const float4*)ctx->d_spheres.p, n, ctx->d_bvh_scratch.p, ctx->d_bvh_scratch.bytes,
+                                               (float4*)ctx->d_bvh_spheres.p, (int*)ctx->d_bvh_index.p, &tree, ctx->stream);
+    if (e != hipSuccess)
+        return fail(ctx, IR_EDEVICE, "device LBVH build of %u spheres, stage %s: %s", n, tree.failed_stage, hipGetErrorString(e));
+    IR_HIP(ctx, pt::lbvh_emit_device((const float4*)ctx->d_spheres.p, n, tree, (float4*)ctx->d_bvh_nodes.p, ctx->stream));
+    uint32_t info[pt::kLbvhInfoWords];
+    IR_HIP(ctx, hipMemcpyAsync(info, tree.info, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *too_deep = info[6] + 1 > pt::kMaxStack;
+    ctx->bvh_nodes = info[7];
+    ctx->bvh_depth = info[6];
+    ctx->bvh_stack = info[6] + 1;
+    ctx->bvh_built_by = IR_BUILD_DEVICE;
+    return IR_OK;
+}
+
+int ensure_bvh(ir_context* ctx) {
+    if (selected_accel(ctx) != pt::kAccelLbvh || ctx->bvh_valid) return IR_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    // fewer than 3 spheres are a single leaf (no radix tree to build)
+    bool on_device = ctx->n_spheres >= 3 &&
+                     (ctx->bvh_build == IR_BUILD_DEVICE || (ctx->bvh_build == IR_BUILD_AUTO && ctx->n_spheres >= kAutoDeviceBuildFrom));
+    if (on_device) {
+        bool too_deep = false;
+        IR_TRY(build_bvh_device(ctx, &too_deep));
+        on_device = !too_deep;
+    }
+    if (!on_device) IR_TRY(build_bvh_host(ctx));
+    ctx->bvh_build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ctx->bvh_valid = true;
     return IR_OK;
 }
@@ -319,7 +367,7 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_stats); release(ctx->d_partials);
     release(ctx->d_wf_queue[0]); release(ctx->d_wf_queue[1]); release(ctx->d_wf_counts); release(ctx->d_wf_values);
     release(ctx->d_wf_prim); release(ctx->d_wf_tileacc);
-    release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index);
+    release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index); release(ctx->d_bvh_scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -410,6 +458,15 @@ int ir_set_accel(ir_context* ctx, int accel) {
         return fail(ctx, IR_ELIMIT, "ir_set_accel: the linear scan stages at most %u spheres in LDS, the scene has %u",
                     pt::kMaxLdsSpheres, ctx->n_spheres);
     ctx->accel = accel;
+    return IR_OK;
+}
+
+int ir_set_accel_build(ir_context* ctx, int build) {
+    if (!ctx) return IR_EINVAL;
+    if (build != IR_BUILD_AUTO && build != IR_BUILD_HOST && build != IR_BUILD_DEVICE)
+        return fail(ctx, IR_EINVAL, "ir_set_accel_build: unknown mode %d", build);
+    if (build != ctx->bvh_build) ctx->bvh_valid = false;
+    ctx->bvh_build = build;
     return IR_OK;
 }
 
@@ -808,6 +865,34 @@ int ir_get_accel_info(ir_context* ctx, int* out_accel, uint32_t* out_nodes, uint
     if (out_accel) *out_accel = (accel == pt::kAccelLbvh) ? IR_ACCEL_LBVH : IR_ACCEL_LINEAR;
     if (out_nodes) *out_nodes = (accel == pt::kAccelLbvh) ? ctx->bvh_nodes : 0;
     if (out_depth) *out_depth = (accel == pt::kAccelLbvh) ? ctx->bvh_depth : 0;
+    return IR_OK;
+}
+
+int ir_get_accel_build_info(ir_context* ctx, int* out_builder, double* out_seconds) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    IR_TRY(ensure_bvh(ctx));
+    const bool lbvh = selected_accel(ctx) == pt::kAccelLbvh;
+    if (out_builder) *out_builder = lbvh ? ctx->bvh_built_by : IR_BUILD_HOST;
+    if (out_seconds) *out_seconds = lbvh ? ctx->bvh_build_seconds : 0.0;
+    return IR_OK;
+}
+
+int ir_download_accel(ir_context* ctx, void* wide_nodes, uint32_t n_nodes, float* leaf_spheres, int32_t* leaf_index, uint32_t n_spheres) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    IR_TRY(ensure_bvh(ctx));
+    if (selected_accel(ctx) != pt::kAccelLbvh) return fail(ctx, IR_ESTATE, "ir_download_accel: the scene is rendered with the linear scan");
+    if (n_nodes != ctx->bvh_nodes || n_spheres != ctx->n_spheres)
+        return fail(ctx, IR_EINVAL, "ir_download_accel: the LBVH has %u nodes over %u spheres, buffers are for %u / %u", ctx->bvh_nodes,
+                    ctx->n_spheres, n_nodes, n_spheres);
+    if (wide_nodes)
+        IR_HIP(ctx, hipMemcpyAsync(wide_nodes, ctx->d_bvh_nodes.p, (size_t)n_nodes * sizeof(pt::WideNode), hipMemcpyDeviceToHost, ctx->stream));
+    if (leaf_spheres)
+        IR_HIP(ctx, hipMemcpyAsync(leaf_spheres, ctx->d_bvh_spheres.p, (size_t)n_spheres * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (leaf_index)
+        IR_HIP(ctx, hipMemcpyAsync(leaf_index, ctx->d_bvh_index.p, (size_t)n_spheres * 4, hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IR_OK;
 }
 

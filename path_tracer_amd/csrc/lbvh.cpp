@@ -50,7 +50,7 @@ struct Builder {
     }
 
     // returns the node index
-    uint32_t build(uint32_t first, uint32_t last, int bit, uint32_t depth) {
+    uint32_t build(uint32_t first, uint32_t last, uint32_t depth) {
         const uint32_t me = (uint32_t)out->nodes.size();
         out->nodes.emplace_back();
         out->max_depth = std::max(out->max_depth, depth);
@@ -61,23 +61,27 @@ struct Builder {
             nd.leaf = (int32_t)(first * 8 + count);
         } else {
             nd.leaf = -1;
-            // split at the highest bit (<= bit) in which the first and last code differ
+            // Binary radix tree over the keys (code, sorted position) — the tree of Karras 2012, which the device
+            // builder (pt_lbvh_build.hip) produces node for node: split where the highest bit in which the first
+            // and last key differ turns 1.  Equal codes continue on the bits of the sorted position.
             uint32_t split = first + count / 2;
-            int b = bit;
             const uint32_t diff = code[order[first]] ^ code[order[last - 1]];
-            if (diff != 0 && !balanced) {
-                while (b >= 0 && !((diff >> b) & 1u)) --b;
-                // first element whose bit b is set (codes are sorted)
-                uint32_t lo_i = first, hi_i = last - 1;
+            if (balanced) {
+                // median
+            } else if (diff != 0) {
+                const int b = 31 - __builtin_clz(diff);
+                uint32_t lo_i = first, hi_i = last - 1;  // first element whose bit b is set (codes are sorted)
                 while (lo_i < hi_i) {
                     const uint32_t mid = (lo_i + hi_i) / 2;
                     if ((code[order[mid]] >> b) & 1u) hi_i = mid; else lo_i = mid + 1;
                 }
                 split = lo_i;
-                --b;
+            } else {
+                const int b = 31 - __builtin_clz(first ^ (last - 1));
+                split = ((last - 1) >> b) << b;
             }
-            const uint32_t l = build(first, split, b, depth + 1);
-            const uint32_t r = build(split, last, b, depth + 1);
+            const uint32_t l = build(first, split, depth + 1);
+            const uint32_t r = build(split, last, depth + 1);
             for (int k = 0; k < 3; ++k) {  // union of the children's boxes (min/max are exact)
                 nd.lo[k] = std::min(out->nodes[l].lo[k], out->nodes[r].lo[k]);
                 nd.hi[k] = std::max(out->nodes[l].hi[k], out->nodes[r].hi[k]);
@@ -127,7 +131,7 @@ static void build_preorder(const float* spheres_xyzr, uint32_t n, Lbvh& out, boo
         return b.code[x] != b.code[y] ? b.code[x] < b.code[y] : x < y;
     });
     out.nodes.reserve((size_t)n + 8);
-    b.build(0, n, 29, 0);
+    b.build(0, n, 0);
     out.leaf_spheres.resize((size_t)n * 4);
     out.leaf_index.resize(n);
     for (uint32_t i = 0; i < n; ++i) {

@@ -115,6 +115,26 @@ class RayTracer:
         _capi.check(self._ctx, _capi.lib.ir_get_accel_info(self._ctx, C.byref(a), C.byref(n), C.byref(d)))
         return {"accel": a.value, "nodes": n.value, "depth": d.value}
 
+    def set_accel_build(self, build):
+        """IR_BUILD_AUTO / IR_BUILD_HOST / IR_BUILD_DEVICE: where the LBVH is (re)built after a scene edit."""
+        _capi.check(self._ctx, _capi.lib.ir_set_accel_build(self._ctx, int(build)))
+
+    def get_accel_build_info(self):
+        b, t = C.c_int(), C.c_double()
+        _capi.check(self._ctx, _capi.lib.ir_get_accel_build_info(self._ctx, C.byref(b), C.byref(t)))
+        return {"builder": b.value, "seconds": t.value}
+
+    def download_accel(self):
+        """LBVH arrays as built: (nodes, 16) f32 wide nodes (refs are int32 bit patterns), (n, 4) leaf spheres, (n,) indices."""
+        info = self.get_accel_info()
+        n = getattr(self, "_n_spheres", 0)
+        wide = np.zeros((info["nodes"], 16), dtype=np.float32)
+        leaf = np.zeros((n, 4), dtype=np.float32)
+        index = np.zeros((n,), dtype=np.int32)
+        _capi.check(self._ctx, _capi.lib.ir_download_accel(self._ctx, wide.ctypes.data_as(C.c_void_p), info["nodes"], _capi.fptr(leaf),
+                                                           index.ctypes.data_as(_capi.c_i32_p), n))
+        return wide, leaf, index
+
     def get_radiance(self):
         """Accumulator.framebuffer / sample_counts (full_buffer.rs:7-12): (h, w, 4) f32 sums and (h, w) u32."""
         w, h = self.get_current_size()
@@ -193,6 +213,7 @@ class RayTracer:
         mats = np.ascontiguousarray(scene.flat_materials(), dtype=np.float32)
         _capi.check(ctx, _capi.lib.ir_set_materials(ctx, _capi.fptr(mats), mats.shape[0]))
         _capi.check(ctx, _capi.lib.ir_set_spheres(ctx, _capi.fptr(xyzr), mid.ctypes.data_as(_capi.c_i32_p), xyzr.shape[0]))
+        self._n_spheres = int(xyzr.shape[0])
         sky = np.asarray(scene.default_sky_color, dtype=np.float32).reshape(3)
         _capi.check(ctx, _capi.lib.ir_set_sky_color(ctx, _capi.fptr(np.ascontiguousarray(sky))))
         box = scene.skybox

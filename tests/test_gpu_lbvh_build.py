@@ -1,0 +1,200 @@
+"""Device LBVH build (pt_lbvh_build.hip) against the host build (lbvh.cpp): the two builders must give byte-identical
+wide nodes, leaf spheres and leaf indices, and therefore the same hits; both equal the reference's linear scan
+(integrator.rs:106-127), checked through the oracle where the scan is affordable.
+
+Scenes cover what the radix tree has to get right: distinct codes, long runs of equal Morton codes (which continue on
+the bits of the sorted position), all spheres at one point, non-finite centres and radii, and the smallest trees, and a count above
+rocPRIM's switch from merge sort to onesweep."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pta():
+    import path_tracer_amd
+    return path_tracer_amd
+
+
+@pytest.fixture(scope="module")
+def tracer(pta):
+    rt = pta.RayTracer(0, 0, device=0)
+    yield rt
+    rt.close()
+
+
+def _scene(xyzr):
+    from path_tracer_amd import workloads as W
+    xyzr = np.ascontiguousarray(xyzr, dtype=np.float32)
+    n = xyzr.shape[0]
+    mats = np.zeros((1, 9), dtype=np.float32)
+    mats[0, :4] = (0.8, 0.7, 0.6, 0.5)
+    return W.FlatScene(xyzr, np.zeros(n, dtype=np.int32), mats, default_sky_color=(0.6, 0.7, 0.9), skybox=None)
+
+
+def _random(n, seed):
+    rng = np.random.default_rng(seed)
+    xyzr = np.empty((n, 4), dtype=np.float32)
+    xyzr[:, 0] = rng.uniform(-40, 40, n)
+    xyzr[:, 1] = rng.uniform(-2, 6, n)
+    xyzr[:, 2] = rng.uniform(-80, 0, n)
+    xyzr[:, 3] = rng.uniform(0.1, 0.6, n)
+    return xyzr
+
+
+def _duplicates(n, seed):
+    """Few distinct centres, many spheres each: runs of equal codes far longer than a leaf."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-10, 10, (7, 3)).astype(np.float32)
+    centres[:, 2] -= 30
+    xyzr = np.empty((n, 4), dtype=np.float32)
+    xyzr[:, :3] = centres[rng.integers(0, 7, n)]
+    xyzr[:, 3] = rng.uniform(0.2, 1.5, n)
+    return xyzr
+
+
+def _one_point(n, seed):
+    rng = np.random.default_rng(seed)
+    xyzr = np.zeros((n, 4), dtype=np.float32)
+    xyzr[:, 2] = -20
+    xyzr[:, 3] = rng.uniform(0.5, 3.0, n)
+    return xyzr
+
+
+def _non_finite(n, seed):
+    xyzr = _random(n, seed)
+    xyzr[5, 0] = np.inf
+    xyzr[17, 1] = np.nan
+    xyzr[40, 3] = np.nan
+    xyzr[41, 3] = np.inf
+    xyzr[77, 3] = -0.4       # negative radius: |r| bounds it, r*r tests it
+    xyzr[90, :3] = (-0.0, 0.0, -0.0)
+    return xyzr
+
+
+def _grid(n, seed):
+    """Lattice: many exact coordinate ties and zero signs."""
+    k = int(round(n ** (1 / 3))) + 1
+    g = np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3)[:n].astype(np.float32)
+    xyzr = np.empty((n, 4), dtype=np.float32)
+    xyzr[:, 0] = g[:, 0] - k // 2
+    xyzr[:, 1] = g[:, 1] - k // 2
+    xyzr[:, 2] = -g[:, 2] * 2 - 5
+    xyzr[:, 3] = 0.3
+    return xyzr
+
+
+SCENES = {
+    "random": _random, "duplicates": _duplicates, "one_point": _one_point, "non_finite": _non_finite, "grid": _grid,
+}
+
+
+def _build(tracer, scene, cam, w, h, build):
+    from path_tracer_amd import _capi
+    tracer.set_accel(_capi.IR_ACCEL_LBVH)
+    tracer.set_accel_build(build)
+    try:
+        idx, t = tracer.get_primary_hits(scene, w, h, with_t=True)
+        info = tracer.get_accel_info()
+        binfo = tracer.get_accel_build_info()
+        arrays = tracer.download_accel()
+    finally:
+        tracer.set_accel_build(_capi.IR_BUILD_AUTO)
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    return idx, t, info, binfo, arrays
+
+
+@pytest.mark.parametrize("kind,n", [
+    ("random", 3), ("random", 4), ("random", 5), ("random", 64), ("random", 1000), ("random", 10000), ("random", 200000), ("random", 2100000),
+    ("duplicates", 300), ("duplicates", 5000), ("one_point", 3), ("one_point", 257), ("non_finite", 2000), ("grid", 4096),
+])
+def test_device_build_equals_host_build(pta, tracer, oracle, kind, n):
+    from path_tracer_amd import _capi, workloads as W
+    w, h = 96, 54
+    xyzr = SCENES[kind](n, 1234 + n)
+    scene = _scene(xyzr)
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    hidx, ht, hinfo, hb, harr = _build(tracer, scene, cam, w, h, _capi.IR_BUILD_HOST)
+    didx, dt, dinfo, db, darr = _build(tracer, scene, cam, w, h, _capi.IR_BUILD_DEVICE)
+    assert hb["builder"] == _capi.IR_BUILD_HOST and db["builder"] == _capi.IR_BUILD_DEVICE
+    assert hinfo == dinfo, (hinfo, dinfo)
+    assert hinfo["nodes"] >= 1 and hinfo["depth"] >= 1
+    for name, a, b in zip(("wide", "leaf_spheres", "leaf_index"), harr, darr):
+        assert a.shape == b.shape, name
+        assert a.tobytes() == b.tobytes(), f"{name}: {np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))} words differ"
+    assert np.array_equal(np.sort(harr[2]), np.arange(n, dtype=np.int32))
+    assert hidx.tobytes() == didx.tobytes() and ht.tobytes() == dt.tobytes()
+    if n <= 10000:
+        oidx, ot = oracle.primary_hits(oracle.camera_from(cam, w, h), scene)
+        assert didx.tobytes() == oidx.tobytes() and dt.tobytes() == ot.tobytes()
+
+
+def test_tree_too_deep_falls_back_to_host(pta, tracer, oracle):
+    """A Morton chain deeper than the traversal stack holds: the device build reports it and the host's median-split tree is used, as with IR_BUILD_HOST."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h = 64, 36
+    n = 400
+    xyzr = np.zeros((n, 4), dtype=np.float32)
+    # codes 1 << b for every b < 30 (one quantised coordinate 2^j on one axis) split off one per level; the run of equal
+    # codes at the origin adds log2(run) levels on the position bits
+    k = 0
+    for j in range(10):
+        for axis in range(3):
+            xyzr[k, axis] = 2.0 ** j / 1024.0
+            k += 1
+    xyzr[k, :3] = 1.0
+    xyzr[:, 3] = 0.3
+    scene = _scene(xyzr)
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    hidx, ht, hinfo, hb, harr = _build(tracer, scene, cam, w, h, _capi.IR_BUILD_HOST)
+    didx, dt, dinfo, db, darr = _build(tracer, scene, cam, w, h, _capi.IR_BUILD_DEVICE)
+    assert hinfo == dinfo and hinfo["depth"] + 1 <= 32
+    for a, b in zip(harr, darr):
+        assert a.tobytes() == b.tobytes()
+    oidx, ot = oracle.primary_hits(oracle.camera_from(cam, w, h), scene)
+    assert didx.tobytes() == oidx.tobytes() and dt.tobytes() == ot.tobytes()
+
+
+def test_rebuild_after_edit_and_auto_choice(pta, tracer, oracle):
+    """The editor's loop: move spheres, render again.  AUTO picks the device builder for large scenes, the host builder
+    for small ones, and each edit gives the scan's hits."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h = 96, 54
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    xyzr = _random(6000, 7)
+    for step in range(3):
+        xyzr[:, 0] += 0.37 * step
+        scene = _scene(xyzr.copy())
+        idx, t = tracer.get_primary_hits(scene, w, h, with_t=True)
+        assert tracer.get_accel_build_info()["builder"] == _capi.IR_BUILD_DEVICE
+        oidx, ot = oracle.primary_hits(oracle.camera_from(cam, w, h), scene)
+        assert idx.tobytes() == oidx.tobytes() and t.tobytes() == ot.tobytes()
+    small = _scene(_random(500, 9))
+    tracer.get_primary_hits(small, w, h)
+    assert tracer.get_accel_build_info()["builder"] == _capi.IR_BUILD_HOST
+
+
+def test_radiance_with_device_built_tree(pta, tracer, oracle):
+    """Bounce rays through the device-built tree: bit-exact sums against the oracle's scan (C3 scene)."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = 96, 54, 4
+    scene = W.scene_s2()
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    tracer.set_integrator(bounces=8, max_compulsory_bounces=2, seed=0x0123456789ABCDEF)
+    tracer.set_accel(_capi.IR_ACCEL_LBVH)
+    tracer.set_accel_build(_capi.IR_BUILD_DEVICE)
+    try:
+        tracer.render(scene, w, h, False, spp=spp)
+        s, c = tracer.get_radiance()
+        assert tracer.get_accel_build_info()["builder"] == _capi.IR_BUILD_DEVICE
+    finally:
+        tracer.set_accel_build(_capi.IR_BUILD_AUTO)
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    os_, oc, _ = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=8, rr_start=2, seed=0x0123456789ABCDEF, math_mode=1)[:3]
+    assert c.tobytes() == oc.tobytes()
+    assert np.array_equal(s.view(np.uint32), os_.view(np.uint32))
