@@ -11,8 +11,7 @@ namespace pt {
 struct LbvhDeviceTree {
     void* info = nullptr;    // uint32[8]: [6] = depth of the deepest node, [7] = wide (inner) node count
     void* order = nullptr;   // sorted position -> original sphere index
-    void* nodes = nullptr;   // int4 per radix-tree node: first, last, split, -
-    void* parent = nullptr;
+    void* nodes = nullptr;   // int4 per radix-tree node: first, last, split, parent
     void* boxes = nullptr;
     const char* failed_stage = "";  // set when lbvh_build_device returns an error
 };

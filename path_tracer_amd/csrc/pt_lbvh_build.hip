@@ -10,8 +10,9 @@
 //   rocprim::radix_sort_pairs    stable, so equal codes keep ascending original index (the host comparator)
 //   lb_radix_tree                Karras 2012: one thread per internal node finds its key range and split;
 //                                equal codes continue on the bits of the sorted position
-//   lb_boxes                     bottom-up: the second child to arrive at a node unions the two boxes (left, right
-//                                order, so the zero signs match the host's too) and counts the node's inner nodes
+//   lb_boxes / lb_boxes_top      bottom-up: the second child to arrive at a node unions the two boxes (left, right
+//                                order, so the zero signs match the host's too) and counts the node's inner nodes;
+//                                nodes inside one workgroup's positions first, the straddling ones in one workgroup
 //   lb_emit                      nodes of >= 3 spheres become 64-byte wide nodes, numbered in pre-order: a node's
 //                                rank is the sum over its ancestors of 1 + (inner nodes of the left sibling subtree)
 //   lb_leaves                    leaf-ordered sphere and index arrays
@@ -47,11 +48,13 @@ __device__ __forceinline__ float max2(float a, float b) { return (a < b) ? b : a
 
 __device__ __forceinline__ bool finite(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
 
+constexpr int kSegments = 64;
+
 __global__ void lb_init(uint32_t* info) {
     const int t = threadIdx.x;
     if (t < 3) info[t] = ordered(INFINITY);
     else if (t < 6) info[t] = ordered(-INFINITY);
-    else if (t < kInfoWords) info[t] = 0u;
+    else if (t < kInfoWords + kSegments) info[t] = 0u;  // [kInfoWords ...) = queue counters of lb_boxes
 }
 
 __global__ void __launch_bounds__(kBlock) lb_centre_bounds(const float4* __restrict__ spheres, uint32_t n, uint32_t* info) {
@@ -120,9 +123,10 @@ __device__ __forceinline__ int delta(const uint32_t* __restrict__ code, int n, i
     return ci != cj ? __clz((int)(ci ^ cj)) : 32 + __clz(i ^ j);
 }
 
-// parent[]: [0, n-1) internal nodes, [n, 2n) sorted positions
-__global__ void __launch_bounds__(kBlock) lb_radix_tree(const uint32_t* __restrict__ code, int n, int4* __restrict__ nodes,
-                                                        int* __restrict__ parent, uint32_t* __restrict__ flags) {
+// nodes[i] = (first, last, split, parent): the first three words are written by node i's thread, the parent word by the
+// parent's thread (-1 for the root, node 0).  leaf_parent[j]: parent of sorted position j.
+__global__ void __launch_bounds__(kBlock) lb_radix_tree(const uint32_t* __restrict__ code, int n, int* __restrict__ nodes,
+                                                        int* __restrict__ leaf_parent, uint32_t* __restrict__ flags) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n - 1) return;
     const uint32_t ci = code[i];
@@ -142,10 +146,14 @@ __global__ void __launch_bounds__(kBlock) lb_radix_tree(const uint32_t* __restri
     }
     const int split = i + s * d + min(d, 0);  // last position of the left child
     const int lo = min(i, j), hi = max(i, j);
-    nodes[i] = make_int4(lo, hi, split, 0);
-    parent[lo == split ? n + split : split] = i;
-    parent[split + 1 == hi ? n + hi : split + 1] = i;
-    if (i == 0) parent[0] = -1;
+    nodes[4 * i + 0] = lo;
+    nodes[4 * i + 1] = hi;
+    nodes[4 * i + 2] = split;
+    if (lo == split) leaf_parent[split] = i;
+    else nodes[4 * split + 3] = i;
+    if (split + 1 == hi) leaf_parent[hi] = i;
+    else nodes[4 * (split + 1) + 3] = i;
+    if (i == 0) nodes[3] = -1;
     flags[i] = 0u;
 }
 
@@ -181,48 +189,96 @@ __device__ __forceinline__ Box load_box(const float4* boxes, int node, int* inne
 }
 
 // boxes[2 * node] = (lo.xyz, inner nodes in the subtree), boxes[2 * node + 1] = (hi.xyz, 0)
-__global__ void __launch_bounds__(kBlock) lb_boxes(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, int n,
-                                                   const int4* __restrict__ nodes, const int* __restrict__ parent, uint32_t* flags,
-                                                   float4* boxes) {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
+//
+// One climb step at node p for the child whose box is `mine`: the first child to arrive leaves (returns false); its
+// stores are released by the atomic and acquired by the second's, which unions the two boxes and carries on.
+// SCOPE is the scope both arrivals at the node share.  An agent-scope release / acquire costs an L2 write-back /
+// invalidate on a multi-XCD part (with every step at agent scope this pass took 5 ms per million spheres), so
+// lb_boxes climbs at workgroup scope as far as a workgroup's positions reach and leaves the rest to lb_boxes_top.
+template <int SCOPE>
+__device__ __forceinline__ bool climb(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, const int4 nd, int p,
+                                      uint32_t* flags, float4* boxes, Box& mine, int& mine_inner, int& mine_lo) {
+    if (__hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_ACQ_REL, SCOPE) == 0u) return false;
+    const bool left = mine_lo == nd.x;
+    Box other;
+    int other_inner = 0;
+    if (left) {
+        if (nd.z + 1 == nd.y) other = sphere_box(spheres, order, nd.y);
+        else other = load_box(boxes, nd.z + 1, &other_inner);
+    } else {
+        if (nd.x == nd.z) other = sphere_box(spheres, order, nd.x);
+        else other = load_box(boxes, nd.z, &other_inner);
+    }
+    const Box& l = left ? mine : other;
+    const Box& r = left ? other : mine;
+    Box u;
+    for (int k = 0; k < 3; ++k) {
+        u.lo[k] = min2(l.lo[k], r.lo[k]);
+        u.hi[k] = max2(l.hi[k], r.hi[k]);
+    }
+    mine = u;
+    mine_inner = (nd.y - nd.x + 1 > (int)kLeafMax) ? 1 + mine_inner + other_inner : 0;
+    mine_lo = nd.x;
+    boxes[2 * p] = make_float4(u.lo[0], u.lo[1], u.lo[2], __int_as_float(mine_inner));
+    boxes[2 * p + 1] = make_float4(u.hi[0], u.hi[1], u.hi[2], 0.0f);
+    return true;
+}
+
+// Pass 1: one thread per sorted position, workgroups of kTopBlock positions.  A thread climbs while the node's positions
+// all belong to its workgroup; at the first node that straddles workgroups it queues (node, child) for pass 2.  Queue
+// segments (one per blockIdx % kSegments) spread the append counters over addresses.
+constexpr int kTopBlock = 1024;
+
+__global__ void __launch_bounds__(kTopBlock) lb_boxes(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, int n,
+                                                      const int4* __restrict__ nodes, const int* __restrict__ leaf_parent, uint32_t* flags,
+                                                      float4* boxes, uint32_t* queue_count, int2* __restrict__ queue, uint32_t segment_cap) {
+    const int j = blockIdx.x * kTopBlock + threadIdx.x;
     if (j >= n) return;
     Box mine = sphere_box(spheres, order, j);
     int mine_inner = 0;
     int mine_lo = j;
-    int p = parent[n + j];
+    int child = n + j;
+    int p = leaf_parent[j];
     while (p >= 0) {
-        // The first child to arrive leaves; its stores are released by this atomic and acquired by the second's.  When
-        // the node's leaves all belong to this workgroup, so do both arrivals, and workgroup scope is enough (no L2
-        // write-back / invalidate, which an agent-scope release / acquire costs on a multi-XCD part): only the few
-        // nodes that straddle workgroups pay for agent scope.
         const int4 nd = nodes[p];
-        const bool local = (nd.x / kBlock) == (nd.y / kBlock);
-        const uint32_t arrived = local ? __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP)
-                                       : __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == 0u) return;
-        const bool left = mine_lo == nd.x;
-        Box other;
-        int other_inner = 0;
-        if (left) {
-            if (nd.z + 1 == nd.y) other = sphere_box(spheres, order, nd.y);
-            else other = load_box(boxes, nd.z + 1, &other_inner);
-        } else {
-            if (nd.x == nd.z) other = sphere_box(spheres, order, nd.x);
-            else other = load_box(boxes, nd.z, &other_inner);
+        if (nd.x / kTopBlock != nd.y / kTopBlock) {
+            const uint32_t seg = blockIdx.x % kSegments;
+            const uint32_t slot = atomicAdd(&queue_count[seg], 1u);
+            queue[(size_t)seg * segment_cap + slot] = make_int2(p, child);
+            return;
         }
-        const Box& l = left ? mine : other;
-        const Box& r = left ? other : mine;
-        Box u;
-        for (int k = 0; k < 3; ++k) {
-            u.lo[k] = min2(l.lo[k], r.lo[k]);
-            u.hi[k] = max2(l.hi[k], r.hi[k]);
-        }
-        mine = u;
-        mine_inner = (nd.y - nd.x + 1 > (int)kLeafMax) ? 1 + mine_inner + other_inner : 0;
-        mine_lo = nd.x;
-        boxes[2 * p] = make_float4(u.lo[0], u.lo[1], u.lo[2], __int_as_float(mine_inner));
-        boxes[2 * p + 1] = make_float4(u.hi[0], u.hi[1], u.hi[2], 0.0f);
-        p = parent[p];
+        if (!climb<__HIP_MEMORY_SCOPE_WORKGROUP>(spheres, order, nd, p, flags, boxes, mine, mine_inner, mine_lo)) return;
+        child = p;
+        p = nd.w;
+    }
+}
+
+// Pass 2: the nodes that straddle pass-1 workgroups (a few per workgroup boundary and level): one thread per queued
+// arrival, agent scope.  It starts from a clean L2 (kernel boundary) and makes few stores, so the write-backs are cheap.
+__global__ void __launch_bounds__(kBlock) lb_boxes_top(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, int n,
+                                                       const int4* __restrict__ nodes, uint32_t* flags, float4* boxes,
+                                                       const uint32_t* __restrict__ queue_count, const int2* __restrict__ queue,
+                                                       uint32_t segment_cap) {
+    const uint32_t seg = blockIdx.y;
+    const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= queue_count[seg]) return;
+    const int2 entry = queue[(size_t)seg * segment_cap + e];
+    Box mine;
+    int mine_inner = 0, mine_lo;
+    if (entry.y >= n) {
+        mine_lo = entry.y - n;
+        mine = sphere_box(spheres, order, mine_lo);
+    } else {
+        mine = load_box(boxes, entry.y, &mine_inner);
+        mine_lo = nodes[entry.y].x;
+    }
+    int4 nd = nodes[entry.x];
+    for (int p = entry.x; p >= 0;) {
+        const int up = nd.w;
+        const int4 next = nodes[up >= 0 ? up : 0];  // in flight while the atomic and the sibling's box are fetched
+        if (!climb<__HIP_MEMORY_SCOPE_AGENT>(spheres, order, nd, p, flags, boxes, mine, mine_inner, mine_lo)) return;
+        p = up;
+        nd = next;
     }
 }
 
@@ -236,19 +292,20 @@ __device__ __forceinline__ void child_entry(const float4* __restrict__ spheres, 
 }
 
 __global__ void __launch_bounds__(kBlock) lb_emit(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, int n,
-                                                  const int4* __restrict__ nodes, const int* __restrict__ parent,
-                                                  const float4* __restrict__ boxes, float4* __restrict__ wide, uint32_t* info) {
+                                                  const int4* __restrict__ nodes, const float4* __restrict__ boxes,
+                                                  float4* __restrict__ wide, uint32_t* info) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n - 1) return;
     const int4 nd = nodes[i];
     if (nd.y - nd.x + 1 <= (int)kLeafMax) return;
     int rank = 0, depth = 0, child_lo = nd.x;
-    for (int p = parent[i]; p >= 0; p = parent[p]) {
+    for (int p = nd.w; p >= 0;) {
         const int4 a = nodes[p];
         rank += 1;
         if (child_lo != a.x && a.z - a.x + 1 > (int)kLeafMax) rank += __float_as_int(boxes[2 * a.z].w);
         child_lo = a.x;
         ++depth;
+        p = a.w;
     }
     const int left_inner = (nd.z - nd.x + 1 > (int)kLeafMax) ? __float_as_int(boxes[2 * nd.z].w) : 0;
     Box bl, br;
@@ -278,6 +335,12 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// pass-1 workgroups per queue segment x entries a workgroup can append (one per position)
+static size_t queue_segment_cap(uint32_t n) {
+    const size_t blocks = ((size_t)n + kTopBlock - 1) / kTopBlock;
+    return (blocks + kSegments - 1) / kSegments * kTopBlock;
+}
+
 size_t lbvh_build_sort_bytes(uint32_t n) {
     size_t b = 0;
     (void)rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n,
@@ -287,8 +350,9 @@ size_t lbvh_build_sort_bytes(uint32_t n) {
 
 size_t lbvh_build_scratch_bytes(uint32_t n) {
     const size_t m = n;
-    return align256(kInfoWords * 4) + 4 * align256(m * 4)   // info, code/index in and out
-           + align256(m * 16) + align256(2 * m * 4)          // nodes, parent
+    return align256((kInfoWords + kSegments) * 4) + 4 * align256(m * 4)   // info, code/index in and out
+           + align256(queue_segment_cap(n) * kSegments * sizeof(int2))
+           + align256(m * 16) + align256(m * 4)              // nodes, leaf_parent
            + align256(m * 4) + align256(m * 32)              // flags, boxes
            + align256(lbvh_build_sort_bytes(n));
 }
@@ -304,13 +368,15 @@ hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch,
         p += align256(bytes);
         return q;
     };
-    uint32_t* info = (uint32_t*)take(kInfoWords * 4);
+    uint32_t* info = (uint32_t*)take((kInfoWords + kSegments) * 4);
+    const uint32_t segment_cap = (uint32_t)queue_segment_cap(n);
+    int2* queue = (int2*)take((size_t)segment_cap * kSegments * sizeof(int2));
     uint32_t* code_in = (uint32_t*)take(m * 4);
     uint32_t* index_in = (uint32_t*)take(m * 4);
     uint32_t* code = (uint32_t*)take(m * 4);
     uint32_t* order = (uint32_t*)take(m * 4);
     int4* nodes = (int4*)take(m * 16);
-    int* parent = (int*)take(2 * m * 4);
+    int* leaf_parent = (int*)take(m * 4);
     uint32_t* flags = (uint32_t*)take(m * 4);
     float4* boxes = (float4*)take(m * 32);
     size_t sort_bytes = lbvh_build_sort_bytes(n);
@@ -324,7 +390,7 @@ hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch,
         tree->failed_stage = name;                \
         return e;                                 \
     }
-    LB_STAGE("lb_init", lb_init<<<1, 64, 0, stream>>>(info))
+    LB_STAGE("lb_init", lb_init<<<1, 128, 0, stream>>>(info))
     LB_STAGE("lb_centre_bounds", lb_centre_bounds<<<min(blocks, 256u), kBlock, 0, stream>>>(d_spheres, n, info))
     LB_STAGE("lb_codes", lb_codes<<<blocks, kBlock, 0, stream>>>(d_spheres, n, info, code_in, index_in))
     e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, code_in, code, index_in, order, (size_t)n, 0u, 30u, stream);
@@ -332,21 +398,23 @@ hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch,
         tree->failed_stage = "radix_sort_pairs";
         return e;
     }
-    LB_STAGE("lb_radix_tree", lb_radix_tree<<<blocks, kBlock, 0, stream>>>(code, (int)n, nodes, parent, flags))
-    LB_STAGE("lb_boxes", lb_boxes<<<blocks, kBlock, 0, stream>>>(d_spheres, order, (int)n, nodes, parent, flags, boxes))
+    LB_STAGE("lb_radix_tree", lb_radix_tree<<<blocks, kBlock, 0, stream>>>(code, (int)n, (int*)nodes, leaf_parent, flags))
+    LB_STAGE("lb_boxes", lb_boxes<<<(n + kTopBlock - 1) / kTopBlock, kTopBlock, 0, stream>>>(d_spheres, order, (int)n, nodes, leaf_parent, flags,
+                                                                                            boxes, info + kInfoWords, queue, segment_cap))
+    LB_STAGE("lb_boxes_top", lb_boxes_top<<<dim3((segment_cap + kBlock - 1) / kBlock, kSegments), kBlock, 0, stream>>>(
+                                 d_spheres, order, (int)n, nodes, flags, boxes, info + kInfoWords, queue, segment_cap))
     LB_STAGE("lb_leaves", lb_leaves<<<blocks, kBlock, 0, stream>>>(d_spheres, order, n, d_leaf_spheres, d_leaf_index))
 #undef LB_STAGE
     tree->info = info;
     tree->order = order;
     tree->nodes = nodes;
-    tree->parent = parent;
     tree->boxes = boxes;
     return hipSuccess;
 }
 
 hipError_t lbvh_emit_device(const float4* d_spheres, uint32_t n, const LbvhDeviceTree& tree, float4* d_wide, hipStream_t stream) {
     const uint32_t blocks = (n + kBlock - 1) / kBlock;
-    lb_emit<<<blocks, kBlock, 0, stream>>>(d_spheres, (const uint32_t*)tree.order, (int)n, (const int4*)tree.nodes, (const int*)tree.parent,
+    lb_emit<<<blocks, kBlock, 0, stream>>>(d_spheres, (const uint32_t*)tree.order, (int)n, (const int4*)tree.nodes,
                                            (const float4*)tree.boxes, d_wide, (uint32_t*)tree.info);
     return hipGetLastError();
 }
