@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
     ap.add_argument("--schedule", choices=["auto", "regeneration", "wavefront"], default="auto",
                     help="integrator schedule (ir_set_schedule); results are identical, only speed differs")
+    ap.add_argument("--sky-sampling", choices=["bsdf", "mis"], default="bsdf",
+                    help="bsdf = the reference's estimator (the metric's); mis = sky importance sampling (extension: one more "
+                         "trace per bounce, far lower variance under a sun-dominated sky; see tools/sky_sampling_convergence.py)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a box with ONE GPU: every rank uses device 0 and the exchange step goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
@@ -136,6 +139,7 @@ def main():
     rt.set_integrator(bounces=BOUNCES, max_compulsory_bounces=RR, seed=Wk.RNG_SEED)
     rt.set_schedule({"auto": _capi.IR_SCHEDULE_AUTO, "regeneration": _capi.IR_SCHEDULE_REGENERATION,
                      "wavefront": _capi.IR_SCHEDULE_WAVEFRONT}[args.schedule])
+    rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
     rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
     # accumulator in torch-owned device memory so that RCCL can reduce it in place
     sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
@@ -230,6 +234,7 @@ def main():
                 "partition": "none" if world == 1 else (f"sample-range x{world}" if partition == "samples" else
                                                        f"64x64 tiles round-robin x{world}") + " + RCCL reduce(sum) to rank 0",
                 "seed": hex(Wk.RNG_SEED),
+                "sky_sampling": args.sky_sampling,
             },
             "roofline": {
                 "bound": "valu",

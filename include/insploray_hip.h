@@ -40,6 +40,7 @@ enum {
 };
 
 enum { IR_SKY_NEAREST = 0, IR_SKY_BILINEAR = 1 };  /* exr.rs:20-23 is NEAREST */
+enum { IR_SKY_SAMPLING_BSDF = 0, IR_SKY_SAMPLING_MIS = 1 };  /* integrator.rs:64-70,84-89 is BSDF */
 enum { IR_PARTITION_NONE = 0, IR_PARTITION_TILES = 1, IR_PARTITION_SAMPLES = 2 };
 enum { IR_ACCEL_AUTO = 0, IR_ACCEL_LINEAR = 1, IR_ACCEL_LBVH = 2 };
 enum { IR_BUILD_AUTO = 0, IR_BUILD_HOST = 1, IR_BUILD_DEVICE = 2 };
@@ -82,6 +83,14 @@ int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h);
  * reference does not have: same u, v; texel centres at (i + 0.5) / n, longitude wraps, latitude clamps,
  * a + (b - a) * t along x then y. */
 int ir_set_sky_filter(ir_context* ctx, int filter);
+/* IR_SKY_SAMPLING_BSDF (default) is the reference's estimator: a bounce direction from its hemisphere sampler
+ * (sampler.rs:43-53), the sky met only when that ray escapes (integrator.rs:84-89).  IR_SKY_SAMPLING_MIS is an
+ * extension for sun-dominated skies (workload C5): at every hit whose bounce ray is traced, a second direction is drawn
+ * from the sky image's own distribution (luminance x solid angle), traced as a shadow ray, and the two strategies are
+ * combined with the balance heuristic.  Same expectation as the reference's estimator, far lower
+ * variance; costs one more trace per bounce.  Needs a skybox (with a constant sky colour it changes nothing); linear
+ * scan and regeneration schedule only, otherwise ir_render fails with IR_ESTATE. */
+int ir_set_sky_sampling(ir_context* ctx, int mode);
 /* Closest-hit structure: IR_ACCEL_LINEAR = the reference's linear scan (integrator.rs:106-127) over an
  * LDS-staged SoA buffer (at most 10 000 spheres); IR_ACCEL_LBVH = linear BVH over the spheres whose (t, index)
  * equals the scan's bit for bit (leaf tests are the scan's arithmetic, node tests are conservative, ties keep the

@@ -24,6 +24,7 @@ IR_SKY_NEAREST, IR_SKY_BILINEAR = 0, 1
 IR_PARTITION_NONE, IR_PARTITION_TILES, IR_PARTITION_SAMPLES = 0, 1, 2
 IR_ACCEL_AUTO, IR_ACCEL_LINEAR, IR_ACCEL_LBVH = 0, 1, 2
 IR_BUILD_AUTO, IR_BUILD_HOST, IR_BUILD_DEVICE = 0, 1, 2
+IR_SKY_SAMPLING_BSDF, IR_SKY_SAMPLING_MIS = 0, 1
 IR_SCHEDULE_AUTO, IR_SCHEDULE_REGENERATION, IR_SCHEDULE_WAVEFRONT = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
@@ -45,6 +46,7 @@ PROTOTYPES = {
     "ir_set_sky_color": (C.c_int, [ctx_p, c_float_p]),
     "ir_set_skybox": (C.c_int, [ctx_p, c_float_p, C.c_uint32, C.c_uint32]),
     "ir_set_sky_filter": (C.c_int, [ctx_p, C.c_int]),
+    "ir_set_sky_sampling": (C.c_int, [ctx_p, C.c_int]),
     "ir_set_accel": (C.c_int, [ctx_p, C.c_int]),
     "ir_get_accel_info": (C.c_int, [ctx_p, C.POINTER(C.c_int), c_u32_p, c_u32_p]),
     "ir_set_accel_build": (C.c_int, [ctx_p, C.c_int]),

@@ -20,6 +20,7 @@
 #include "lbvh.h"
 #include "pt_lbvh_build.h"
 #include "pt_kernels.h"
+#include "sky_distribution.h"
 
 namespace {
 
@@ -58,6 +59,9 @@ struct ir_context {
     DeviceBuf d_skybox;
     uint32_t sky_w = 0, sky_h = 0;
     int sky_filter = IR_SKY_NEAREST;
+    int sky_sampling = IR_SKY_SAMPLING_BSDF;
+    DeviceBuf d_sky_marginal, d_sky_cond, d_sky_pdf;
+    bool sky_tables_valid = false;
     int accel = IR_ACCEL_AUTO;
 
     // camera
@@ -274,6 +278,23 @@ int ensure_bvh(ir_context* ctx) {
     return IR_OK;
 }
 
+// Sky importance sampling tables, built on the host from the texels as they are on the device (ir_set_skybox keeps no
+// host copy) the first time a render needs them.
+int ensure_sky_tables(ir_context* ctx) {
+    if (ctx->sky_tables_valid) return IR_OK;
+    const uint32_t w = ctx->sky_w, h = ctx->sky_h;
+    std::vector<float> texels((size_t)w * h * 4);
+    IR_HIP(ctx, hipMemcpyAsync(texels.data(), ctx->d_skybox.p, texels.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pt::SkyDistribution d;
+    pt::build_sky_distribution(texels.data(), w, h, d);
+    IR_TRY(upload(ctx, ctx->d_sky_marginal, d.marginal.data(), d.marginal.size() * sizeof(float)));
+    IR_TRY(upload(ctx, ctx->d_sky_cond, d.cond.data(), d.cond.size() * sizeof(float)));
+    IR_TRY(upload(ctx, ctx->d_sky_pdf, d.pdf.data(), d.pdf.size() * sizeof(float)));
+    ctx->sky_tables_valid = true;
+    return IR_OK;
+}
+
 void fill_bvh(const ir_context* ctx, pt::LbvhView& v) {
     v.wide = (const float4*)ctx->d_bvh_nodes.p;
     v.leaf_spheres = (const float4*)ctx->d_bvh_spheres.p;
@@ -368,6 +389,7 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_wf_queue[0]); release(ctx->d_wf_queue[1]); release(ctx->d_wf_counts); release(ctx->d_wf_values);
     release(ctx->d_wf_prim); release(ctx->d_wf_tileacc);
     release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index); release(ctx->d_bvh_scratch);
+    release(ctx->d_sky_marginal); release(ctx->d_sky_cond); release(ctx->d_sky_pdf);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -422,6 +444,7 @@ int ir_set_sky_color(ir_context* ctx, const float rgb[3]) {
 int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h) {
     if (!ctx) return IR_EINVAL;
     IR_TRY(use_device(ctx));
+    ctx->sky_tables_valid = false;
     if (!rgb) {
         IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         release(ctx->d_skybox);
@@ -447,6 +470,13 @@ int ir_set_sky_filter(ir_context* ctx, int filter) {
     if (!ctx) return IR_EINVAL;
     if (filter != IR_SKY_NEAREST && filter != IR_SKY_BILINEAR) return fail(ctx, IR_EINVAL, "ir_set_sky_filter: unknown filter %d", filter);
     ctx->sky_filter = filter;
+    return IR_OK;
+}
+
+int ir_set_sky_sampling(ir_context* ctx, int mode) {
+    if (!ctx) return IR_EINVAL;
+    if (mode != IR_SKY_SAMPLING_BSDF && mode != IR_SKY_SAMPLING_MIS) return fail(ctx, IR_EINVAL, "ir_set_sky_sampling: unknown mode %d", mode);
+    ctx->sky_sampling = mode;
     return IR_OK;
 }
 
@@ -555,6 +585,16 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     IR_TRY(ensure(ctx, ctx->d_spheres, 16));
     IR_TRY(ensure_bvh(ctx));
     const int accel = selected_accel(ctx);
+    // sky importance sampling needs a sky image; with a constant sky colour there is nothing to importance-sample
+    const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
+    if (skymis) {
+        if (accel != pt::kAccelLinear)
+            return fail(ctx, IR_ESTATE, "ir_render: IR_SKY_SAMPLING_MIS is implemented for the linear scan only (%u spheres select the LBVH)",
+                        ctx->n_spheres);
+        if (ctx->schedule == IR_SCHEDULE_WAVEFRONT)
+            return fail(ctx, IR_ESTATE, "ir_render: IR_SKY_SAMPLING_MIS is implemented for the regeneration schedule only");
+        IR_TRY(ensure_sky_tables(ctx));
+    }
 
     pt::RenderArgs a;
     memset(&a, 0, sizeof(a));
@@ -571,6 +611,11 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     a.sky_w = ctx->sky_w;
     a.sky_h = ctx->sky_h;
     a.sky_filter = ctx->sky_filter;
+    if (skymis) {
+        a.sky_marginal = (const float*)ctx->d_sky_marginal.p;
+        a.sky_cond = (const float*)ctx->d_sky_cond.p;
+        a.sky_pdf = (const float*)ctx->d_sky_pdf.p;
+    }
     a.bounces = ctx->bounces;
     a.rr_start = ctx->rr_start;
     a.seed_lo = (uint32_t)(ctx->seed & 0xffffffffu);

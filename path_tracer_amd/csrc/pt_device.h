@@ -545,6 +545,90 @@ PT_DEV f3 sky_bilinear(const float4* __restrict__ sky, uint32_t sw, uint32_t sh,
     return top + (bot - top) * ty;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Sky importance sampling (IR_SKY_SAMPLING_MIS; extension, the reference samples the BSDF only).
+// The reference's hemisphere sample (sampler.rs:43-53) is (r cos, r sin, 1 - r), r = sqrt(r2), NOT normalised; its
+// direction has solid-angle density 1 / (pi (sin t + cos t)^3) around the normal (t = polar angle), which equals
+// L^3 / pi for L = |(r, 1 - r)|, and its path weight brdf cos / pdf is the albedo whatever the direction.  So a bounce
+// estimates albedo * integral(density(w) sky(w) visible(w)): a second strategy that draws w from the sky's own
+// distribution estimates the same integral, and the two are combined with the balance heuristic.  Plain IEEE
+// operations in a fixed order (the oracle restates them).
+// ----------------------------------------------------------------------------------------------------
+struct SkyTables {
+    const float* marginal;  // h + 1
+    const float* cond;      // h x (w + 1)
+    const float* pdf;       // h x w, see sky_distribution.h
+};
+constexpr uint32_t kSkyDrawBase = 0x40000000u;  // draw indices of the sky strategy: kSkyDrawBase + 2 * bounce + {0, 1}
+
+// largest i in [0, n) with cdf[i] <= x (cdf[0] == 0 <= x < 1 == cdf[n])
+PT_DEV uint32_t cdf_find(const float* __restrict__ cdf, uint32_t n, float x) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+PT_DEV float cdf_frac(float x, float c0, float c1) {
+    const float f = (x - c0) / (c1 - c0);
+    return f > 0.99999994f ? 0.99999994f : f;
+}
+PT_DEV float bsdf_density_dir(float cos_n) {  // from the unit direction's cosine to the normal
+    float s2 = 1.0f - cos_n * cos_n;
+    if (s2 < 0.0f) s2 = 0.0f;
+    const float sc = sqrt_cr(s2) + cos_n;
+    float t = sc * sc;
+    t = t * sc;
+    t = kPi * t;
+    return 1.0f / t;
+}
+PT_DEV float bsdf_density_r(float r) {  // from the sampler's radius
+    const float q = 1.0f - r;
+    const float l2 = r * r + q * q;
+    return (l2 * sqrt_cr(l2)) / kPi;
+}
+PT_DEV float sky_density(const SkyTables& t, size_t texel, float sin_polar) {
+    return sin_polar > 0.0f ? t.pdf[texel] / sin_polar : 0.0f;
+}
+// Direction drawn from the sky distribution: texel (ix, iy), a point inside it, unit direction ws, sin of its polar angle.
+PT_DEV void sky_sample(const SkyTables& t, uint32_t sw, uint32_t sh, float x1, float x2, uint32_t& ix, uint32_t& iy, f3& ws,
+                       float& sin_polar) {
+    iy = cdf_find(t.marginal, sh, x1);
+    const float fy = cdf_frac(x1, t.marginal[iy], t.marginal[iy + 1]);
+    const float* row = t.cond + (size_t)iy * (sw + 1);
+    ix = cdf_find(row, sw, x2);
+    const float fx = cdf_frac(x2, row[ix], row[ix + 1]);
+    const float u = ((float)ix + fx) / (float)sw;
+    const float v = ((float)iy + fy) / (float)sh;
+    const float theta = v * kPi, phi = u * kTwoPi;
+    float st, ct, sp, cp;
+    sincos_poly(theta, st, ct);
+    sincos_poly(phi, sp, cp);
+    ws = mk3(-(st * cp), ct, -(st * sp));
+    sin_polar = st;
+}
+// The lookup of sky_nearest / sky_bilinear plus what the balance weight of a BSDF-sampled ray needs: the nearest texel
+// (the sky distribution's cell) and the sine of the polar angle.
+PT_DEV f3 sky_lookup_mis(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, int bilinear, f3 dir, size_t& texel,
+                         float& sin_polar) {
+    const f3 d = normalize(dir);
+    float cy = d.y;
+    cy = (cy < -1.0f) ? -1.0f : cy;
+    cy = (cy > 1.0f) ? 1.0f : cy;
+    float s2 = 1.0f - cy * cy;
+    if (s2 < 0.0f) s2 = 0.0f;
+    sin_polar = sqrt_cr(s2);
+    float u, v;
+    sky_uv(dir, u, v);
+    const uint32_t x = texel_index(u * (float)sw, sw);
+    const uint32_t y = texel_index(v * (float)sh, sh);
+    texel = (size_t)y * sw + x;
+    if (bilinear) return sky_bilinear(sky, sw, sh, dir);
+    const float4 t = sky[texel];
+    return mk3(t.x, t.y, t.z);
+}
+
 // integrator.rs:66-70: cos = max(wi.n, 0); pdf = cos / PI; contribution *= (brdf * cos) / pdf.
 // `fast_materials` (host, per scene): every brdf component is +0 or in [2^-30, 2^30], so with cos in [2^-60, 2^60]
 // pdf is in the mid range, brdf*cos is +0 or >= 2^-90 and the quotient (~ albedo) is +0 or in [2^-29, 2^32].

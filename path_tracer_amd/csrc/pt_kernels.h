@@ -28,6 +28,10 @@ struct RenderArgs {
     const float4* skybox;  // rgb padded to float4, row 0 first; nullptr => constant sky
     uint32_t sky_w, sky_h;
     int sky_filter;
+    // sky importance sampling tables (sky_distribution.h); all nullptr => BSDF sampling only, as the reference
+    const float* sky_marginal;
+    const float* sky_cond;
+    const float* sky_pdf;
 
     uint32_t bounces, rr_start;
     uint32_t seed_lo, seed_hi;

@@ -39,7 +39,9 @@ __device__ __forceinline__ float4 sphere_at(const Args& a, const float4* s_sph, 
     }
 }
 
-template <int ACCEL, bool STATS>
+// SKYMIS: sky importance sampling (IR_SKY_SAMPLING_MIS, pt_device.h): one more direction per traced bounce, drawn from
+// the sky's distribution and traced as a shadow ray; both strategies weighted with the balance heuristic.
+template <int ACCEL, bool STATS, bool SKYMIS>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
             int idx = idx0;
             f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
             if (STATS) { n_traces = 1; n_disc = disc0; n_hits = 1; }
+            const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf};
 
             while (s < spp) {
                 // ---- shade the hit of bounce b (integrator.rs:50-81)
@@ -131,6 +134,35 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
                     const f3 d = wi;
                     ++b;
                     if (b < B) {
+                        float ray_density = 0.0f;
+                        if constexpr (SKYMIS) {
+                            ray_density = bsdf_density_r(sqrt_cr(r2));
+                            uint32_t ix, iy;
+                            f3 ws;
+                            float sin_polar;
+                            sky_sample(sky_tables, a.sky_w, a.sky_h, draw(skey, kSkyDrawBase + 2 * (b - 1)),
+                                       draw(skey, kSkyDrawBase + 2 * (b - 1) + 1), ix, iy, ws, sin_polar);
+                            const float c = dot(ws, nrm);
+                            if (c > 0.0f && sin_polar > 0.0f) {
+                                const size_t texel = (size_t)iy * a.sky_w + ix;
+                                const float pe = sky_density(sky_tables, texel, sin_polar);
+                                const float pa = bsdf_density_dir(c);
+                                const float wgt = pa / (pe + pa);
+                                const uint32_t before = wc.disc;
+                                const HitRec hs = trace_any<ACCEL, STATS>(a, s_sph, o, ws, wc);
+                                if (STATS) { n_traces++; n_disc += wc.disc - before; }
+                                if (hs.idx < 0) {
+                                    f3 sk;
+                                    if (a.sky_filter == 1) {
+                                        sk = sky_bilinear(a.skybox, a.sky_w, a.sky_h, ws);
+                                    } else {
+                                        const float4 t = a.skybox[texel];
+                                        sk = mk3(t.x, t.y, t.z);
+                                    }
+                                    light = light + (sk * contrib) * wgt;
+                                }
+                            }
+                        }
                         const uint32_t before = wc.disc;
                         const HitRec h = trace_any<ACCEL, STATS>(a, s_sph, o, d, wc);
                         if (STATS) { n_traces++; n_disc += wc.disc - before; }
@@ -140,7 +172,15 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
                             hit_geometry(sp, o, d, h.t, pos, nrm);
                             idx = h.idx;
                         } else {
-                            light = light + sky_eval(a, d) * contrib;
+                            if constexpr (SKYMIS) {
+                                size_t texel;
+                                float sin_polar;
+                                const f3 sk = sky_lookup_mis(a.skybox, a.sky_w, a.sky_h, a.sky_filter, d, texel, sin_polar);
+                                const float pe = sky_density(sky_tables, texel, sin_polar);
+                                light = light + (sk * contrib) * (ray_density / (ray_density + pe));
+                            } else {
+                                light = light + sky_eval(a, d) * contrib;
+                            }
                             done = true;
                         }
                     } else {
@@ -414,9 +454,13 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
 hipError_t init_kernels() {
     hipError_t e;
     const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
-    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)primary_hits_kernel<kAccelLinear>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     return e;
@@ -442,10 +486,13 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         // occupancy experiments only (tools/): IR_DEBUG_LDS_PAD=<bytes> pads the workgroup's LDS allocation
         static const size_t pad = getenv("IR_DEBUG_LDS_PAD") ? (size_t)atol(getenv("IR_DEBUG_LDS_PAD")) : 0;
         if (lds + pad <= kMaxLdsSpheres * sizeof(float4)) lds += pad;
+        const bool skymis = a.sky_marginal != nullptr;
         if (stats) {
-            hipLaunchKernelGGL((render_kernel<kAccelLinear, true>), grid, block, lds, stream, a);
+            if (skymis) hipLaunchKernelGGL((render_kernel<kAccelLinear, true, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((render_kernel<kAccelLinear, true, false>), grid, block, lds, stream, a);
         } else {
-            hipLaunchKernelGGL((render_kernel<kAccelLinear, false>), grid, block, lds, stream, a);
+            if (skymis) hipLaunchKernelGGL((render_kernel<kAccelLinear, false, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((render_kernel<kAccelLinear, false, false>), grid, block, lds, stream, a);
         }
     }
     hipError_t e = hipGetLastError();

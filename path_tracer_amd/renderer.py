@@ -110,6 +110,10 @@ class RayTracer:
         """IR_SKY_NEAREST (reference, exr.rs:20-23) or IR_SKY_BILINEAR (extension)."""
         _capi.check(self._ctx, _capi.lib.ir_set_sky_filter(self._ctx, int(sky_filter)))
 
+    def set_sky_sampling(self, mode):
+        """IR_SKY_SAMPLING_BSDF (reference, integrator.rs:64-70,84-89) or IR_SKY_SAMPLING_MIS (extension)."""
+        _capi.check(self._ctx, _capi.lib.ir_set_sky_sampling(self._ctx, int(mode)))
+
     def get_accel_info(self):
         a, n, d = C.c_int(), C.c_uint32(), C.c_uint32()
         _capi.check(self._ctx, _capi.lib.ir_get_accel_info(self._ctx, C.byref(a), C.byref(n), C.byref(d)))

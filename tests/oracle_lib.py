@@ -43,6 +43,8 @@ lib.orc_sample_hemisphere.argtypes = [_f, C.c_float, C.c_float, C.c_int, _f]
 lib.orc_sky_lookup.argtypes = [_f, C.c_uint32, C.c_uint32, _f, C.c_int, _f]
 lib.orc_set_sky_filter.argtypes = [C.c_int]
 lib.orc_set_sample_block.argtypes = [C.c_uint32]
+lib.orc_set_sky_sampling.argtypes = [C.c_int]
+lib.orc_sky_distribution.argtypes = [_f, C.c_uint32, C.c_uint32, _f, _f, _f]
 lib.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.orc_rng_draw.restype = C.c_float
 lib.orc_rng_mix32.argtypes = [C.c_uint32]
@@ -183,6 +185,22 @@ def sky_lookup(box, d, math_mode=0):
 def set_sky_filter(f):
     """0 = nearest (the reference), 1 = bilinear (the build's extension); process-global."""
     lib.orc_set_sky_filter(int(f))
+
+
+def set_sky_sampling(mode):
+    """0 = BSDF sampling only (the reference), 1 = sky importance sampling with MIS (the build's extension); process-global."""
+    lib.orc_set_sky_sampling(int(mode))
+
+
+def sky_distribution(box):
+    """(marginal (h+1,), cond (h, w+1), pdf (h, w)) of the sky importance-sampling tables."""
+    w, h = box.width, box.height
+    buf = np.ascontiguousarray(box.pixels_buffer, dtype=np.float32)
+    m = np.zeros(h + 1, dtype=np.float32)
+    c = np.zeros((h, w + 1), dtype=np.float32)
+    p = np.zeros((h, w), dtype=np.float32)
+    lib.orc_sky_distribution(_fp(buf), w, h, _fp(m), _fp(c), _fp(p))
+    return m, c, p
 
 
 def set_sample_block(n):
