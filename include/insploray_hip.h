@@ -43,7 +43,7 @@ enum { IR_SKY_NEAREST = 0, IR_SKY_BILINEAR = 1 };  /* exr.rs:20-23 is NEAREST */
 enum { IR_SKY_SAMPLING_BSDF = 0, IR_SKY_SAMPLING_MIS = 1 };  /* integrator.rs:64-70,84-89 is BSDF */
 enum { IR_PARTITION_NONE = 0, IR_PARTITION_TILES = 1, IR_PARTITION_SAMPLES = 2 };
 enum { IR_ACCEL_AUTO = 0, IR_ACCEL_LINEAR = 1, IR_ACCEL_LBVH = 2 };
-enum { IR_BUILD_AUTO = 0, IR_BUILD_HOST = 1, IR_BUILD_DEVICE = 2 };
+enum { IR_BUILD_AUTO = 0, IR_BUILD_HOST = 1, IR_BUILD_DEVICE = 2, IR_BUILD_REFIT = 3 };
 enum { IR_SCHEDULE_AUTO = 0, IR_SCHEDULE_REGENERATION = 1, IR_SCHEDULE_WAVEFRONT = 2 };
 
 /* ABI version of this header (bumped on incompatible change). */
@@ -103,9 +103,13 @@ int ir_get_accel_info(ir_context* ctx, int* out_accel, uint32_t* out_nodes, uint
  * frames; the reference itself has nothing to rebuild).  IR_BUILD_HOST: Morton sort and top-down splits on the CPU,
  * arrays uploaded.  IR_BUILD_DEVICE: the same tree built by kernels from the spheres already on the device (radix
  * sort, Karras radix tree, bottom-up boxes), byte-identical arrays; a tree too deep for the traversal stack falls
- * back to the host's median-split build.  IR_BUILD_AUTO (default): device from 2048 spheres. */
+ * back to the host's median-split build.  IR_BUILD_AUTO (default): device from 2048 spheres.  IR_BUILD_REFIT: device
+ * build when the sphere count changed (or first), otherwise the previous tree is kept and only its boxes follow the
+ * moved spheres (no sort, no tree construction): for edits that move spheres a little, frame after frame.  Hits stay
+ * the scan's bit for bit with any valid tree; traversal gets slower the further the spheres stray from where the tree
+ * was built, so select IR_BUILD_DEVICE again (or change the count) to rebuild. */
 int ir_set_accel_build(ir_context* ctx, int build);
-/* Builder that produced the current LBVH (IR_BUILD_HOST / IR_BUILD_DEVICE) and the wall time of that build in
+/* Builder that produced the current LBVH (IR_BUILD_HOST / IR_BUILD_DEVICE / IR_BUILD_REFIT) and the wall time of that build in
  * seconds, uploads and synchronisation included.  Builds the LBVH if it is selected and stale. */
 int ir_get_accel_build_info(ir_context* ctx, int* out_builder, double* out_seconds);
 /* Copies the LBVH arrays to the host (for inspection and tests): n_nodes x 64-byte wide nodes (layout in

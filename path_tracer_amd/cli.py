@@ -79,6 +79,8 @@ def main(argv=None):
     ap.add_argument("--rr-start", type=int, default=2, help="max_compulsory_bounces, reference default 2 (renderer.rs:40)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=W.RNG_SEED)
     ap.add_argument("--sky-filter", choices=["nearest", "bilinear"], default="nearest")
+    ap.add_argument("--sky-sampling", choices=["bsdf", "mis"], default="bsdf",
+                    help="bsdf: the reference's estimator; mis: sky importance sampling (extension, linear scan only)")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", help="image to write: .exr (linear mean radiance) or .ppm (resolved frame)")
@@ -93,6 +95,7 @@ def main(argv=None):
         rt.set_active_camera(cam)
         rt.set_integrator(bounces=args.bounces, max_compulsory_bounces=args.rr_start, seed=args.seed)
         rt.set_sky_filter(_capi.IR_SKY_BILINEAR if args.sky_filter == "bilinear" else _capi.IR_SKY_NEAREST)
+        rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
         rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
         resumed = 0
         if args.resume:

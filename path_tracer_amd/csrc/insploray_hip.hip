@@ -54,6 +54,7 @@ struct ir_context {
     bool bvh_valid = false;
     int bvh_build = IR_BUILD_AUTO;
     int bvh_built_by = IR_BUILD_HOST;
+    uint32_t bvh_topology_n = 0;  // sphere count whose device-built radix tree is still in d_bvh_scratch (0 = none)
     double bvh_build_seconds = 0.0;
     float sky[3] = {0.0f, 0.0f, 0.0f};
     DeviceBuf d_skybox;
@@ -240,13 +241,15 @@ int build_bvh_host(ir_context* ctx) {
 // *too_deep: the radix tree needs more than kMaxStack stack entries (the host builder then falls back to median splits).
 int build_bvh_device(ir_context* ctx, bool* too_deep) {
     const uint32_t n = ctx->n_spheres;
+    const bool refit = ctx->bvh_build == IR_BUILD_REFIT && ctx->bvh_topology_n == n;
+    ctx->bvh_topology_n = 0;
     IR_TRY(ensure(ctx, ctx->d_bvh_scratch, pt::lbvh_build_scratch_bytes(n)));
     IR_TRY(ensure(ctx, ctx->d_bvh_spheres, (size_t)n * 16));
     IR_TRY(ensure(ctx, ctx->d_bvh_index, (size_t)n * 4));
     IR_TRY(ensure(ctx, ctx->d_bvh_nodes, (size_t)(n - 1) * sizeof(pt::WideNode)));
     pt::LbvhDeviceTree tree;
     const hipError_t e = pt::lbvh_build_device((const float4*)ctx->d_spheres.p, n, ctx->d_bvh_scratch.p, ctx->d_bvh_scratch.bytes,
-                                               (float4*)ctx->d_bvh_spheres.p, (int*)ctx->d_bvh_index.p, &tree, ctx->stream);
+                                               (float4*)ctx->d_bvh_spheres.p, (int*)ctx->d_bvh_index.p, &tree, refit, ctx->stream);
     if (e != hipSuccess)
         return fail(ctx, IR_EDEVICE, "device LBVH build of %u spheres, stage %s: %s", n, tree.failed_stage, hipGetErrorString(e));
     IR_HIP(ctx, pt::lbvh_emit_device((const float4*)ctx->d_spheres.p, n, tree, (float4*)ctx->d_bvh_nodes.p, ctx->stream));
@@ -257,7 +260,8 @@ int build_bvh_device(ir_context* ctx, bool* too_deep) {
     ctx->bvh_nodes = info[7];
     ctx->bvh_depth = info[6];
     ctx->bvh_stack = info[6] + 1;
-    ctx->bvh_built_by = IR_BUILD_DEVICE;
+    ctx->bvh_built_by = refit ? IR_BUILD_REFIT : IR_BUILD_DEVICE;
+    if (!*too_deep) ctx->bvh_topology_n = n;
     return IR_OK;
 }
 
@@ -266,7 +270,8 @@ int ensure_bvh(ir_context* ctx) {
     const auto t0 = std::chrono::steady_clock::now();
     // fewer than 3 spheres are a single leaf (no radix tree to build)
     bool on_device = ctx->n_spheres >= 3 &&
-                     (ctx->bvh_build == IR_BUILD_DEVICE || (ctx->bvh_build == IR_BUILD_AUTO && ctx->n_spheres >= kAutoDeviceBuildFrom));
+                     (ctx->bvh_build == IR_BUILD_DEVICE || ctx->bvh_build == IR_BUILD_REFIT ||
+                      (ctx->bvh_build == IR_BUILD_AUTO && ctx->n_spheres >= kAutoDeviceBuildFrom));
     if (on_device) {
         bool too_deep = false;
         IR_TRY(build_bvh_device(ctx, &too_deep));
@@ -493,9 +498,12 @@ int ir_set_accel(ir_context* ctx, int accel) {
 
 int ir_set_accel_build(ir_context* ctx, int build) {
     if (!ctx) return IR_EINVAL;
-    if (build != IR_BUILD_AUTO && build != IR_BUILD_HOST && build != IR_BUILD_DEVICE)
+    if (build != IR_BUILD_AUTO && build != IR_BUILD_HOST && build != IR_BUILD_DEVICE && build != IR_BUILD_REFIT)
         return fail(ctx, IR_EINVAL, "ir_set_accel_build: unknown mode %d", build);
-    if (build != ctx->bvh_build) ctx->bvh_valid = false;
+    if (build != ctx->bvh_build) {
+        ctx->bvh_valid = false;
+        ctx->bvh_topology_n = 0;  // the first build in a new mode is a full one
+    }
     ctx->bvh_build = build;
     return IR_OK;
 }

@@ -21,8 +21,11 @@ constexpr int kLbvhInfoWords = 8;
 size_t lbvh_build_scratch_bytes(uint32_t n);
 
 // Radix tree, boxes and the leaf-ordered arrays (n x float4 and n x int) of n >= 3 spheres (cx, cy, cz, r).
+// refit: keep the sorted order and the tree of the previous call with the same n and the same scratch buffer, recompute
+// only what depends on the spheres' coordinates (boxes, leaf arrays).  The result is a valid tree of the moved spheres
+// (every box bounds its subtree), not the tree a fresh build would make.
 hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch, size_t scratch_bytes, float4* d_leaf_spheres,
-                             int* d_leaf_index, LbvhDeviceTree* tree, hipStream_t stream);
+                             int* d_leaf_index, LbvhDeviceTree* tree, bool refit, hipStream_t stream);
 
 // Wide nodes in pre-order into d_wide (room for n - 1 nodes of 64 bytes); fills info[6] and info[7].
 hipError_t lbvh_emit_device(const float4* d_spheres, uint32_t n, const LbvhDeviceTree& tree, float4* d_wide, hipStream_t stream);

@@ -358,7 +358,7 @@ size_t lbvh_build_scratch_bytes(uint32_t n) {
 }
 
 hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch, size_t scratch_bytes, float4* d_leaf_spheres,
-                             int* d_leaf_index, LbvhDeviceTree* tree, hipStream_t stream) {
+                             int* d_leaf_index, LbvhDeviceTree* tree, bool refit, hipStream_t stream) {
     tree->failed_stage = "arguments";
     if (n < 3 || scratch_bytes < lbvh_build_scratch_bytes(n)) return hipErrorInvalidValue;
     const size_t m = n;
@@ -391,14 +391,23 @@ hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch,
         return e;                                 \
     }
     LB_STAGE("lb_init", lb_init<<<1, 128, 0, stream>>>(info))
-    LB_STAGE("lb_centre_bounds", lb_centre_bounds<<<min(blocks, 256u), kBlock, 0, stream>>>(d_spheres, n, info))
-    LB_STAGE("lb_codes", lb_codes<<<blocks, kBlock, 0, stream>>>(d_spheres, n, info, code_in, index_in))
-    e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, code_in, code, index_in, order, (size_t)n, 0u, 30u, stream);
-    if (e != hipSuccess) {
-        tree->failed_stage = "radix_sort_pairs";
-        return e;
+    if (refit) {
+        // order, nodes and leaf_parent of the previous build of these n spheres are still in the scratch buffer: only the
+        // boxes (and with them the wide nodes and the leaf arrays) follow the moved spheres
+        if ((e = hipMemsetAsync(flags, 0, m * 4, stream)) != hipSuccess) {
+            tree->failed_stage = "memset";
+            return e;
+        }
+    } else {
+        LB_STAGE("lb_centre_bounds", lb_centre_bounds<<<min(blocks, 256u), kBlock, 0, stream>>>(d_spheres, n, info))
+        LB_STAGE("lb_codes", lb_codes<<<blocks, kBlock, 0, stream>>>(d_spheres, n, info, code_in, index_in))
+        e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, code_in, code, index_in, order, (size_t)n, 0u, 30u, stream);
+        if (e != hipSuccess) {
+            tree->failed_stage = "radix_sort_pairs";
+            return e;
+        }
+        LB_STAGE("lb_radix_tree", lb_radix_tree<<<blocks, kBlock, 0, stream>>>(code, (int)n, (int*)nodes, leaf_parent, flags))
     }
-    LB_STAGE("lb_radix_tree", lb_radix_tree<<<blocks, kBlock, 0, stream>>>(code, (int)n, (int*)nodes, leaf_parent, flags))
     LB_STAGE("lb_boxes", lb_boxes<<<(n + kTopBlock - 1) / kTopBlock, kTopBlock, 0, stream>>>(d_spheres, order, (int)n, nodes, leaf_parent, flags,
                                                                                             boxes, info + kInfoWords, queue, segment_cap))
     LB_STAGE("lb_boxes_top", lb_boxes_top<<<dim3((segment_cap + kBlock - 1) / kBlock, kSegments), kBlock, 0, stream>>>(

@@ -178,6 +178,49 @@ def test_rebuild_after_edit_and_auto_choice(pta, tracer, oracle):
     assert tracer.get_accel_build_info()["builder"] == _capi.IR_BUILD_HOST
 
 
+def test_refit_keeps_tree_and_follows_spheres(pta, tracer, oracle):
+    """IR_BUILD_REFIT: full device build first, then only the boxes follow the edits; hits stay the scan's even after
+    moves the tree was not built for; a changed sphere count rebuilds."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h = 96, 54
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    rng = np.random.default_rng(5)
+    xyzr = _random(6000, 21)
+    tracer.set_accel(_capi.IR_ACCEL_LBVH)
+    tracer.set_accel_build(_capi.IR_BUILD_REFIT)
+    try:
+        tracer.get_primary_hits(_scene(xyzr), w, h)
+        assert tracer.get_accel_build_info()["builder"] == _capi.IR_BUILD_DEVICE
+        wide0, leaf0, index0 = tracer.download_accel()
+        for step in range(3):
+            xyzr = xyzr.copy()
+            xyzr[:, :3] += rng.normal(0, 0.05 * (step + 1), (6000, 3)).astype(np.float32)
+            xyzr[rng.integers(0, 6000, 20), :3] += rng.normal(0, 15.0, (20, 3)).astype(np.float32)  # a few stray far
+            xyzr[rng.integers(0, 6000, 5), 3] *= 4.0
+            scene = _scene(xyzr)
+            idx, t = tracer.get_primary_hits(scene, w, h, with_t=True)
+            assert tracer.get_accel_build_info()["builder"] == _capi.IR_BUILD_REFIT
+            wide, leaf, index = tracer.download_accel()
+            assert index.tobytes() == index0.tobytes()                      # same leaf order ...
+            assert np.array_equal(wide.view(np.int32)[:, [3, 7]], wide0.view(np.int32)[:, [3, 7]])  # ... same tree ...
+            assert np.array_equal(leaf[:, :3], xyzr[index, :3])             # ... new spheres
+            oidx, ot = oracle.primary_hits(oracle.camera_from(cam, w, h), scene)
+            assert idx.tobytes() == oidx.tobytes() and t.tobytes() == ot.tobytes()
+        # radiance through the refitted tree (bounce rays)
+        tracer.set_integrator(bounces=4, max_compulsory_bounces=2, seed=7)
+        tracer.render(scene, w, h, False, spp=2)
+        s, c = tracer.get_radiance()
+        os_, oc = oracle.render(oracle.camera_from(cam, w, h), scene, 2, bounces=4, rr_start=2, seed=7, math_mode=1)[:2]
+        assert np.array_equal(s.view(np.uint32), os_.view(np.uint32))
+        # another sphere count: nothing to refit
+        tracer.get_primary_hits(_scene(_random(6001, 22)), w, h)
+        assert tracer.get_accel_build_info()["builder"] == _capi.IR_BUILD_DEVICE
+    finally:
+        tracer.set_accel_build(_capi.IR_BUILD_AUTO)
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+
+
 def test_radiance_with_device_built_tree(pta, tracer, oracle):
     """Bounce rays through the device-built tree: bit-exact sums against the oracle's scan (C3 scene)."""
     from path_tracer_amd import _capi, workloads as W
