@@ -80,7 +80,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=W.RNG_SEED)
     ap.add_argument("--sky-filter", choices=["nearest", "bilinear"], default="nearest")
     ap.add_argument("--sky-sampling", choices=["bsdf", "mis"], default="bsdf",
-                    help="bsdf: the reference's estimator; mis: sky importance sampling (extension, linear scan only)")
+                    help="bsdf: the reference's estimator; mis: sky importance sampling (extension)")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", help="image to write: .exr (linear mean radiance) or .ppm (resolved frame)")

@@ -596,9 +596,6 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     // sky importance sampling needs a sky image; with a constant sky colour there is nothing to importance-sample
     const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
     if (skymis) {
-        if (accel != pt::kAccelLinear)
-            return fail(ctx, IR_ESTATE, "ir_render: IR_SKY_SAMPLING_MIS is implemented for the linear scan only (%u spheres select the LBVH)",
-                        ctx->n_spheres);
         if (ctx->schedule == IR_SCHEDULE_WAVEFRONT)
             return fail(ctx, IR_ESTATE, "ir_render: IR_SKY_SAMPLING_MIS is implemented for the regeneration schedule only");
         IR_TRY(ensure_sky_tables(ctx));

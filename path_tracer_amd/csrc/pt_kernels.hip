@@ -235,8 +235,10 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
 constexpr uint32_t kShadeBatch = 32;   // run the shading block when this many lanes wait for it
 constexpr uint32_t kStepsPerRound = 8; // traversal steps between two looks at the wave's state
 
-template <bool STATS>
-__global__ __launch_bounds__(256, 6) void render_lbvh_kernel(const RenderArgs a) {
+// SKYMIS (sky importance sampling, see render_kernel): the shadow ray is one more traversal of the lane's state machine,
+// run before the bounce ray, which waits in registers (direction, density, the strategy's weighted sky term).
+template <bool STATS, bool SKYMIS>
+__global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const RenderArgs a) {
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
     const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
@@ -291,6 +293,11 @@ __global__ __launch_bounds__(256, 6) void render_lbvh_kernel(const RenderArgs a)
     cur.cur = kCursorDone;
     bool traversing = false;  // cur holds an unfinished traversal
     bool landed = false;      // cur holds a finished traversal whose result has not been consumed yet
+    // SKYMIS only: cur is the shadow ray of the sky strategy; the bounce ray (pos + nrm * kEps, wi_next) follows it
+    bool shadow = false;
+    f3 wi_next = mk3(0, 0, 0), sky_term = mk3(0, 0, 0);
+    float ray_density = 0.0f;
+    const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf};
 
     for (;;) {
         const bool waiting = !traversing && s < spp;
@@ -302,16 +309,29 @@ __global__ __launch_bounds__(256, 6) void render_lbvh_kernel(const RenderArgs a)
                 if (landed) {  // consume the finished traversal (integrator.rs:50-51, 82-90)
                     landed = false;
                     if (STATS) { n_traces++; }
-                    if (cur.idx >= 0) {
+                    if (SKYMIS && shadow) {
+                        if (cur.idx < 0) light = light + sky_term;
+                        shadow = false;
+                        cursor_begin(cur, pos + nrm * kEps, wi_next);
+                        traversing = true;
+                    } else if (cur.idx >= 0) {
                         if (STATS) n_hits++;
                         hit_geometry(a.spheres[cur.idx], cur.o, cur.d, cur.best, pos, nrm);
                         idx = cur.idx;
                     } else {
-                        light = light + sky_eval(a, cur.d) * contrib;
+                        if constexpr (SKYMIS) {
+                            size_t texel;
+                            float sin_polar;
+                            const f3 sk = sky_lookup_mis(a.skybox, a.sky_w, a.sky_h, a.sky_filter, cur.d, texel, sin_polar);
+                            const float pe = sky_density(sky_tables, texel, sin_polar);
+                            light = light + (sk * contrib) * (ray_density / (ray_density + pe));
+                        } else {
+                            light = light + sky_eval(a, cur.d) * contrib;
+                        }
                         idx = -1;  // sample finished
                     }
                 }
-                for (;;) {
+                if (!SKYMIS || !traversing) for (;;) {
                     if (idx < 0) {  // finish the sample, regenerate at the primary hit
                         acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
                         ++s;
@@ -344,6 +364,33 @@ __global__ __launch_bounds__(256, 6) void render_lbvh_kernel(const RenderArgs a)
                     if (!done) {
                         ++b;
                         if (b < B) {
+                            if constexpr (SKYMIS) {
+                                ray_density = bsdf_density_r(sqrt_cr(r2));
+                                uint32_t ix, iy;
+                                f3 ws;
+                                float sin_polar;
+                                sky_sample(sky_tables, a.sky_w, a.sky_h, draw(skey, kSkyDrawBase + 2 * (b - 1)),
+                                           draw(skey, kSkyDrawBase + 2 * (b - 1) + 1), ix, iy, ws, sin_polar);
+                                const float c = dot(ws, nrm);
+                                if (c > 0.0f && sin_polar > 0.0f) {
+                                    const size_t texel = (size_t)iy * a.sky_w + ix;
+                                    const float pe = sky_density(sky_tables, texel, sin_polar);
+                                    const float pa = bsdf_density_dir(c);
+                                    f3 sk;
+                                    if (a.sky_filter == 1) {
+                                        sk = sky_bilinear(a.skybox, a.sky_w, a.sky_h, ws);
+                                    } else {
+                                        const float4 t = a.skybox[texel];
+                                        sk = mk3(t.x, t.y, t.z);
+                                    }
+                                    sky_term = (sk * contrib) * (pa / (pe + pa));
+                                    wi_next = wi;
+                                    shadow = true;
+                                    cursor_begin(cur, pos + nrm * kEps, ws);
+                                    traversing = true;
+                                    break;
+                                }
+                            }
                             cursor_begin(cur, pos + nrm * kEps, wi);
                             traversing = true;
                             break;
@@ -476,10 +523,13 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     const dim3 grid(a.wgs_per_layer * a.n_blocks), block(256);
     if (accel == kAccelLbvh) {
         const size_t lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int);
+        const bool skymis = a.sky_marginal != nullptr;
         if (stats) {
-            hipLaunchKernelGGL((render_lbvh_kernel<true>), grid, block, lds, stream, a);
+            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<true, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((render_lbvh_kernel<true, false>), grid, block, lds, stream, a);
         } else {
-            hipLaunchKernelGGL((render_lbvh_kernel<false>), grid, block, lds, stream, a);
+            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<false, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((render_lbvh_kernel<false, false>), grid, block, lds, stream, a);
         }
     } else {
         size_t lds = (size_t)a.n_spheres * sizeof(float4);

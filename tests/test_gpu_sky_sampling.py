@@ -58,6 +58,36 @@ def test_bit_exact_same_stream(pta, mis, oracle, sky, bounces, rr):
     assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
 
 
+@pytest.mark.parametrize("sky_filter", ["nearest", "bilinear"])
+def test_lbvh_kernel_bit_exact(pta, mis, oracle, sky_filter):
+    """The LBVH integrator runs the shadow ray as one more traversal of its lane state machine: same sums as the oracle's
+    scan, on the 3-sphere scene (forced LBVH) and on 10 000 spheres under a sky image."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = 96, 54, 6
+    mis.set_integrator(bounces=8, max_compulsory_bounces=2, seed=SEED)
+    mis.set_accel(_capi.IR_ACCEL_LBVH)
+    if sky_filter == "bilinear":
+        mis.set_sky_filter(_capi.IR_SKY_BILINEAR)
+        oracle.set_sky_filter(1)
+    try:
+        for scene, cam in ((W.scene_s1(), W.default_camera(w, h)),
+                           (W.scene_s2(skybox=W.synthetic_sky(256, 128, sun_scale=500.0)), W.camera_s2(w, h))):
+            mis.set_active_camera(cam)
+            mis.enable_stats()
+            mis.render(scene, w, h, False, spp=spp)
+            s, c = mis.get_radiance()
+            st = mis.get_stats()
+            assert mis.get_accel_info()["accel"] == _capi.IR_ACCEL_LBVH
+            os_, oc, _, ost = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=8, rr_start=2, seed=SEED,
+                                            math_mode=1, want_stats=True)
+            assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
+            assert {k: st[k] for k in ("samples", "traces", "tests", "hits")} == {k: ost[k] for k in ("samples", "traces", "tests", "hits")}
+    finally:
+        mis.set_accel(_capi.IR_ACCEL_AUTO)
+        mis.set_sky_filter(_capi.IR_SKY_NEAREST)
+        oracle.set_sky_filter(0)
+
+
 def test_bilinear_filter_and_stats(pta, mis, oracle):
     from path_tracer_amd import _capi, workloads as W
     w, h, spp = 128, 72, 8
@@ -148,14 +178,8 @@ def test_constant_sky_unchanged_and_unsupported_combinations(pta, mis, oracle):
     b, _ = mis.get_radiance()
     assert a.tobytes() == b.tobytes()
     mis.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS)
-    # LBVH and wavefront: reported, not silently rendered with another estimator
+    # wavefront schedule: reported, not silently rendered with another estimator
     sky_scene = W.scene_s1()
-    mis.set_accel(_capi.IR_ACCEL_LBVH)
-    try:
-        with pytest.raises(pta.InsplorayError):
-            mis.render(sky_scene, w, h, False, spp=spp)
-    finally:
-        mis.set_accel(_capi.IR_ACCEL_AUTO)
     mis.set_schedule(_capi.IR_SCHEDULE_WAVEFRONT)
     try:
         with pytest.raises(pta.InsplorayError):
