@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
     ap.add_argument("--schedule", choices=["auto", "regeneration", "wavefront"], default="auto",
                     help="integrator schedule (ir_set_schedule); results are identical, only speed differs")
+    ap.add_argument("--bounces", type=int, default=None,
+                    help="path depth (the metric is quoted at 8; the reference's own default is 5, renderer.rs:39)")
     ap.add_argument("--sky-sampling", choices=["bsdf", "mis"], default="bsdf",
                     help="bsdf = the reference's estimator (the metric's); mis = sky importance sampling (extension: one more "
                          "trace per bounce, far lower variance under a sun-dominated sky; see tools/sky_sampling_convergence.py)")
@@ -87,6 +89,9 @@ def main():
                     help="N > 1 rehearsal on a box with ONE GPU: every rank uses device 0 and the exchange step goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
     args = ap.parse_args()
+    global BOUNCES
+    if args.bounces is not None:
+        BOUNCES = args.bounces
 
     import numpy as np
     import torch
