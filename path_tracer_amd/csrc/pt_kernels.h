@@ -42,7 +42,6 @@ struct RenderArgs {
     // partials: n_blocks x (w*h) float4 scratch (unused when the launch has a single block).
     uint32_t sample_block;
     uint32_t n_blocks, wgs_per_layer;  // filled in by launch_render
-    uint32_t shade_batch, steps_per_round;  // LBVH kernel schedule, filled in by launch_render
     float4* partials;
 
     float4* sum;       // running radiance sum (rgb) + sample weight (a)
