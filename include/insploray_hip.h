@@ -191,6 +191,11 @@ int ir_synchronize(ir_context* ctx);
 /* RayTracer::get_output (renderer.rs:164-169): resolve (mean, Reinhard, gamma 1/2.2, clamp, 0xAARRGGBB) on the
  * device and copy n = width*height u32 pixels to `out`.  Row 0 is the bottom row, as in the reference. */
 int ir_get_output_argb(ir_context* ctx, uint32_t* out, size_t n);
+/* The same frame as a borrowed slice, which is what RayTracer::get_output returns (`&[u32]`, renderer.rs:164-169):
+ * *out points at width*height pixels in page-locked host memory owned by the context (the device copies straight into
+ * it, no staging: 0.25 instead of 0.5 ms per 1080p frame), valid until the next ir_map_output_argb, resize or
+ * ir_destroy.  *out = NULL and *out_n = 0 for an empty frame; out_n may be NULL. */
+int ir_map_output_argb(ir_context* ctx, const uint32_t** out, size_t* out_n);
 /* Raw accumulator (Accumulator.framebuffer / sample_counts, full_buffer.rs:7-12): n x 4 floats, n x u32. */
 int ir_get_radiance(ir_context* ctx, float* sum_rgba, uint32_t* counts, size_t n);
 /* Overwrite the accumulator (checkpoint restore / tests).  Either pointer may be NULL (left unchanged). */

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "ir_set_sky_color": (C.c_int, [ctx_p, c_float_p]),
     "ir_set_skybox": (C.c_int, [ctx_p, c_float_p, C.c_uint32, C.c_uint32]),
     "ir_set_sky_filter": (C.c_int, [ctx_p, C.c_int]),
+    "ir_map_output_argb": (C.c_int, [ctx_p, C.POINTER(c_u32_p), C.POINTER(C.c_size_t)]),
     "ir_set_sky_sampling": (C.c_int, [ctx_p, C.c_int]),
     "ir_set_accel": (C.c_int, [ctx_p, C.c_int]),
     "ir_get_accel_info": (C.c_int, [ctx_p, C.POINTER(C.c_int), c_u32_p, c_u32_p]),

@@ -91,6 +91,8 @@ struct ir_context {
     // film
     uint32_t width = 0, height = 0;
     DeviceBuf d_sum, d_counts, d_argb, d_hit_idx, d_hit_t;
+    uint32_t* h_argb = nullptr;  // pinned host frame handed out by ir_map_output_argb
+    size_t h_argb_bytes = 0;
     void* ext_sum = nullptr;
     void* ext_counts = nullptr;
     uint32_t ext_w = 0, ext_h = 0;
@@ -389,6 +391,7 @@ void ir_destroy(ir_context* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_rays);
+    if (ctx->h_argb) (void)hipHostFree(ctx->h_argb);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
     release(ctx->d_stats); release(ctx->d_partials);
     release(ctx->d_wf_queue[0]); release(ctx->d_wf_queue[1]); release(ctx->d_wf_counts); release(ctx->d_wf_values);
@@ -760,6 +763,33 @@ int ir_get_output_argb(ir_context* ctx, uint32_t* out, size_t n) {
     IR_HIP(ctx, pt::launch_resolve(film_sum(ctx), film_counts(ctx), (uint32_t*)ctx->d_argb.p, n, ctx->stream));
     IR_HIP(ctx, hipMemcpyAsync(out, ctx->d_argb.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IR_OK;
+}
+
+int ir_map_output_argb(ir_context* ctx, const uint32_t** out, size_t* out_n) {
+    if (!ctx) return IR_EINVAL;
+    if (!out) return fail(ctx, IR_EINVAL, "ir_map_output_argb: NULL");
+    const size_t n = (size_t)ctx->width * ctx->height;
+    *out = nullptr;
+    if (out_n) *out_n = n;
+    if (n == 0) return IR_OK;
+    IR_TRY(use_device(ctx));
+    if (ctx->h_argb_bytes < n * sizeof(uint32_t)) {
+        if (ctx->h_argb) (void)hipHostFree(ctx->h_argb);
+        ctx->h_argb = nullptr;
+        ctx->h_argb_bytes = 0;
+        const hipError_t e = hipHostMalloc((void**)&ctx->h_argb, n * sizeof(uint32_t), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            ctx->h_argb = nullptr;
+            return fail(ctx, IR_ENOMEM, "hipHostMalloc(%zu bytes): %s", n * sizeof(uint32_t), hipGetErrorString(e));
+        }
+        ctx->h_argb_bytes = n * sizeof(uint32_t);
+    }
+    IR_TRY(ensure(ctx, ctx->d_argb, n * sizeof(uint32_t)));
+    IR_HIP(ctx, pt::launch_resolve(film_sum(ctx), film_counts(ctx), (uint32_t*)ctx->d_argb.p, n, ctx->stream));
+    IR_HIP(ctx, hipMemcpyAsync(ctx->h_argb, ctx->d_argb.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = ctx->h_argb;
     return IR_OK;
 }
 

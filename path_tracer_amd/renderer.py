@@ -70,13 +70,12 @@ class RayTracer:
 
     def get_output(self):
         """renderer.rs:164-169: resolved 0xAARRGGBB pixels, row 0 = bottom row (the frontend flips)."""
-        w, h = self.get_current_size()
-        n = w * h
-        if self._frame.size != n:
-            self._frame = np.full(n, 0xFF000000, dtype=np.uint32)  # full_buffer.rs:97-99
-        if n:
-            _capi.check(self._ctx, _capi.lib.ir_get_output_argb(self._ctx, self._frame.ctypes.data_as(_capi.c_u32_p), n))
-        return self._frame
+        # a borrowed slice, as in the reference: valid until the next get_output / resize / close
+        p, n = _capi.c_u32_p(), C.c_size_t()
+        _capi.check(self._ctx, _capi.lib.ir_map_output_argb(self._ctx, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
 
     def get_last_render_time(self):
         """renderer.rs:171-173, seconds."""

@@ -24,6 +24,7 @@ extern "C" {
     pub fn ir_set_sky_color(ctx: *mut ir_context, rgb: *const c_float) -> c_int;
     pub fn ir_set_skybox(ctx: *mut ir_context, rgb: *const c_float, w: u32, h: u32) -> c_int;
     pub fn ir_set_sky_filter(ctx: *mut ir_context, filter: c_int) -> c_int;
+    pub fn ir_map_output_argb(ctx: *mut ir_context, out: *mut *const u32, out_n: *mut usize) -> c_int;
     pub fn ir_set_sky_sampling(ctx: *mut ir_context, mode: c_int) -> c_int;
     pub fn ir_set_accel(ctx: *mut ir_context, accel: c_int) -> c_int;
     pub fn ir_get_accel_info(ctx: *mut ir_context, out_accel: *mut c_int, out_nodes: *mut u32, out_depth: *mut u32) -> c_int;

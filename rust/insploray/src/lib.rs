@@ -42,7 +42,9 @@ pub mod renderer {
             let _ = (&scene, acc);
         }
         pub fn get_output(&mut self) -> &[u32] {
-            // unsafe { sys::ir_get_output_argb(self.ctx, self.frame_buffer.as_mut_ptr(), self.frame_buffer.len()) }
+            // let (mut p, mut n) = (std::ptr::null(), 0usize);
+            // unsafe { sys::ir_map_output_argb(self.ctx, &mut p, &mut n); std::slice::from_raw_parts(p, n) }
+            // (page-locked memory owned by the context, valid until the next call: the borrow on &mut self says the same)
             &self.frame_buffer
         }
     }

@@ -145,3 +145,20 @@ def test_limits_are_errors_not_crashes(pta, tracer):
     tracer.set_active_camera(W.default_camera(32, 18))
     tracer.render(scene, 32, 18, False, spp=2)
     assert (tracer.get_radiance()[1] == 2).all()
+
+
+def test_mapped_output_equals_copied_output(pta, tracer):
+    """ir_map_output_argb (the reference's borrowed `&[u32]`, renderer.rs:164-169) against ir_get_output_argb's copy."""
+    import ctypes as C
+    from path_tracer_amd import _capi, workloads as W
+    for (w, h) in ((97, 61), (320, 180), (97, 61)):
+        scene = W.scene_s1()
+        tracer.set_active_camera(W.default_camera(w, h))
+        tracer.render(scene, w, h, False, spp=3)
+        mapped = tracer.get_output()
+        copied = np.zeros(w * h, dtype=np.uint32)
+        _capi.check(tracer._ctx, _capi.lib.ir_get_output_argb(tracer._ctx, copied.ctypes.data_as(_capi.c_u32_p), w * h))
+        assert mapped.shape == (w * h,) and mapped.tobytes() == copied.tobytes()
+        assert (mapped >> 24 == 0xBA).all()  # alpha of a rendered pixel: Reinhard(1) ** (1/2.2) * 255 truncated
+    with pytest.raises(pta.InsplorayError):
+        _capi.check(tracer._ctx, _capi.lib.ir_map_output_argb(tracer._ctx, None, None))
