@@ -311,3 +311,48 @@ def test_errors_are_reported_not_fatal(pta, tracer):
         tracer.set_partition(_capi.IR_PARTITION_TILES, 5, 2)
     with pytest.raises(pta.InsplorayError):
         pta.RayTracer(4, 4, device=4096)
+
+
+@pytest.mark.parametrize("w,h,spp,bounces", [(97, 61, 1, 8), (160, 90, 3, 8), (64, 64, 4, 5), (33, 17, 2, 0), (1, 1, 1, 8)])
+def test_lbvh_low_spp_matches_oracle(pta, tracer, oracle, w, h, spp, bounces):
+    """Launches of a few samples per pixel with the LBVH (the frontend's redraw asks for one, app.rs:84-99): same sums as
+    the oracle's scan, frame edges that cut 16x16 blocks, zero depth, accumulation over successive calls."""
+    from path_tracer_amd import _capi, workloads as W
+    scene = W.scene_s2(n=3000, skybox=W.synthetic_sky(128, 64))
+    cam = W.camera_s2(w, h)
+    _setup(pta, tracer, scene, cam, bounces, 2)
+    tracer.set_accel(_capi.IR_ACCEL_LBVH)
+    try:
+        tracer.render(scene, w, h, False, spp=spp)
+        tracer.render(scene, w, h, True, spp=spp)
+        s, c = tracer.get_radiance()
+        assert tracer.get_accel_info()["accel"] == _capi.IR_ACCEL_LBVH
+    finally:
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    ocam = oracle.camera_from(cam, w, h)
+    os_, oc, _, _ = oracle.render(ocam, scene, spp, bounces=bounces, rr_start=2, seed=SEED, math_mode=1)
+    os_, oc, _, _ = oracle.render(ocam, scene, spp, bounces=bounces, rr_start=2, seed=SEED, math_mode=1, sample_base=spp, sums=os_, counts=oc)
+    assert c.tobytes() == oc.tobytes()
+    assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
+
+
+def test_lbvh_low_spp_tile_partition(pta, tracer, oracle):
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = 200, 120, 2
+    scene = W.scene_s2(n=2000)
+    cam = W.camera_s2(w, h)
+    _setup(pta, tracer, scene, cam, 8, 2)
+    tracer.set_accel(_capi.IR_ACCEL_LBVH)
+    try:
+        total = np.zeros((h, w, 4), dtype=np.float32)
+        for rank in range(3):
+            tracer.set_partition(_capi.IR_PARTITION_TILES, rank, 3)
+            tracer.render(scene, w, h, False, spp=spp)
+            s, c = tracer.get_radiance()
+            total += s
+        tracer.set_partition(_capi.IR_PARTITION_NONE, 0, 1)
+    finally:
+        tracer.set_partition(_capi.IR_PARTITION_NONE, 0, 1)
+        tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    os_, oc, _, _ = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1)
+    assert np.array_equal(total.view(np.uint32), os_.view(np.uint32))
