@@ -256,6 +256,10 @@ const char* ir_exr_last_error(void);
 /* Writer (fixtures, "save image" — a reference TODO, README.md:104): RGB scanline EXR; compression 0 = NONE,
  * 1 = RLE, 2 = ZIPS, 3 = ZIP, 4 = PIZ, 5 = PXR24 (rounds FLOAT samples to 24 bits); pixel_type 1 = HALF, 2 = FLOAT. */
 int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int compression, int pixel_type);
+/* The resolved frame as an 8-bit RGB PNG (the other half of "save image"): argb as ir_get_output_argb /
+ * ir_map_output_argb return it (0xAARRGGBB, row 0 = bottom row, renderer.rs:164-169), written top-down; alpha is
+ * dropped (it is the constant 0xBA).  Errors through ir_exr_last_error.  Needs no GPU. */
+int ir_png_save(const char* path, const uint32_t* argb, uint32_t w, uint32_t h);
 void ir_free(void* p);
 /* Host restatement of ExrImage::sample (exr.rs:13-24) so the façade keeps that public method. */
 int ir_exr_sample(const float* rgb, uint32_t w, uint32_t h, const float dir[3], float out_rgb[3]);

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "ir_exr_load": (C.c_int, [C.c_char_p, C.POINTER(c_float_p), c_u32_p, c_u32_p]),
     "ir_exr_last_error": (C.c_char_p, []),
     "ir_exr_save": (C.c_int, [C.c_char_p, c_float_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    "ir_png_save": (C.c_int, [C.c_char_p, c_u32_p, C.c_uint32, C.c_uint32]),
     "ir_free": (None, [C.c_void_p]),
     "ir_exr_sample": (C.c_int, [c_float_p, C.c_uint32, C.c_uint32, c_float_p, c_float_p]),
 }

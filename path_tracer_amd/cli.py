@@ -11,7 +11,7 @@ Scene JSON (all fields optional except spheres):
      "spheres": [{"position": [x,y,z], "radius": r, "material_id": i}],
      "camera": {"position": [x,y,z], "rotation": [rx,ry,rz], "focal_length": 35, "sensor_size": 55}}
 
-Outputs: .exr = linear mean radiance (sum / count), .ppm = the reference's resolved 0xAARRGGBB frame
+Outputs: .exr = linear mean radiance (sum / count), .png / .ppm = the reference's resolved 0xAARRGGBB frame
 (full_buffer.rs:49-65) flipped to top-down as the frontend displays it (app.rs:101-104); the checkpoint is the raw
 accumulator (Accumulator.framebuffer / sample_counts) plus the number of samples, so a resumed render continues the
 same counter-based sample sequence.  Prints one JSON line of metrics.
@@ -25,7 +25,7 @@ import numpy as np
 
 from . import _capi, workloads as W
 from .cameras import PinholeCamera
-from .file_formats import ExrImage
+from .file_formats import ExrImage, save_png
 from .renderer import RayTracer
 from .scene import Matrial, Scene, Sphere
 
@@ -83,7 +83,7 @@ def main(argv=None):
                     help="bsdf: the reference's estimator; mis: sky importance sampling (extension)")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--out", help="image to write: .exr (linear mean radiance) or .ppm (resolved frame)")
+    ap.add_argument("--out", help="image to write: .exr (linear mean radiance), .png or .ppm (resolved frame)")
     ap.add_argument("--checkpoint", help="write the accumulator (.npz) after rendering")
     ap.add_argument("--resume", help="load an accumulator (.npz) written by --checkpoint and add --spp more samples")
     args = ap.parse_args(argv)
@@ -114,7 +114,9 @@ def main(argv=None):
         if args.checkpoint:
             np.savez(args.checkpoint, sums=sums, counts=counts, size=np.array([w, h]), samples=np.array(resumed + args.spp))
         if args.out:
-            if args.out.lower().endswith(".ppm"):
+            if args.out.lower().endswith(".png"):
+                save_png(args.out, rt.get_output(), w, h)
+            elif args.out.lower().endswith(".ppm"):
                 write_ppm(args.out, rt.get_output(), w, h)
             else:
                 mean = sums[..., :3] / np.maximum(counts, 1)[..., None].astype(np.float32)

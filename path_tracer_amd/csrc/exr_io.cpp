@@ -630,3 +630,53 @@ int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// PNG writer for the resolved frame ("save image" is a reference TODO, README.md:104): 8-bit RGB, one zlib stream,
+// filter 0 on every row.  argb: 0xAARRGGBB as ir_get_output_argb returns it, row 0 = BOTTOM row (renderer.rs:164-169;
+// the frontend flips it when presenting), written top-down.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+void png_chunk(std::vector<uint8_t>& o, const char type[4], const uint8_t* data, size_t n) {
+    const uint32_t len = (uint32_t)n;
+    const uint8_t l[4] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len};
+    o.insert(o.end(), l, l + 4);
+    const size_t at = o.size();
+    o.insert(o.end(), type, type + 4);
+    if (n) o.insert(o.end(), data, data + n);
+    const uint32_t c = (uint32_t)crc32(0L, o.data() + at, (uInt)(n + 4));
+    const uint8_t cb[4] = {(uint8_t)(c >> 24), (uint8_t)(c >> 16), (uint8_t)(c >> 8), (uint8_t)c};
+    o.insert(o.end(), cb, cb + 4);
+}
+}  // namespace
+
+int ir_png_save(const char* path, const uint32_t* argb, uint32_t w, uint32_t h) {
+    if (!path || !argb || w == 0 || h == 0) return set_err(IR_EINVAL, "ir_png_save: NULL or empty image");
+    if ((uint64_t)w * h > (1ull << 28)) return set_err(IR_ELIMIT, "ir_png_save: image too large");
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (1 + 3 * (size_t)w));
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint32_t* row = argb + (size_t)(h - 1 - y) * w;
+        raw.push_back(0);  // filter type None
+        for (uint32_t x = 0; x < w; ++x) {
+            raw.push_back((uint8_t)(row[x] >> 16));
+            raw.push_back((uint8_t)(row[x] >> 8));
+            raw.push_back((uint8_t)row[x]);
+        }
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return set_err(IR_EIO, "ir_png_save: deflate failed");
+    std::vector<uint8_t> o = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    const uint8_t ihdr[13] = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w,
+                              (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h,
+                              8, 2, 0, 0, 0};  // 8 bits, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+    png_chunk(o, "IHDR", ihdr, sizeof(ihdr));
+    png_chunk(o, "IDAT", z.data(), zlen);
+    png_chunk(o, "IEND", nullptr, 0);
+    FILE* f = fopen(path, "wb");
+    if (!f) return set_err(IR_EIO, std::string("ir_png_save: cannot open ") + path);
+    const bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
+    if (fclose(f) != 0 || !ok) return set_err(IR_EIO, std::string("ir_png_save: write failed: ") + path);
+    return IR_OK;
+}

@@ -49,3 +49,14 @@ class ExrImage:
                                    int(compression), int(pixel_type))
         if rc != _capi.IR_OK:
             raise _capi.InsplorayError(rc, _capi.lib.ir_exr_last_error().decode("utf-8", "replace"))
+
+
+def save_png(path, argb, width, height):
+    """Extension ("save image" is a reference TODO): the resolved 0xAARRGGBB frame of RayTracer.get_output (row 0 =
+    bottom row) as an 8-bit RGB PNG, written top-down."""
+    a = np.ascontiguousarray(argb, dtype=np.uint32).reshape(-1)
+    if a.size != width * height:
+        raise ValueError(f"frame has {a.size} pixels, expected {width}x{height}")
+    rc = _capi.lib.ir_png_save(str(path).encode(), a.ctypes.data_as(_capi.c_u32_p), int(width), int(height))
+    if rc != _capi.IR_OK:
+        raise _capi.InsplorayError(rc, _capi.lib.ir_exr_last_error().decode("utf-8", "replace"))

@@ -64,6 +64,7 @@ extern "C" {
     pub fn ir_exr_load(path: *const c_char, out_rgb: *mut *mut c_float, out_w: *mut u32, out_h: *mut u32) -> c_int;
     pub fn ir_exr_last_error() -> *const c_char;
     pub fn ir_exr_save(path: *const c_char, rgb: *const c_float, w: u32, h: u32, compression: c_int, pixel_type: c_int) -> c_int;
+    pub fn ir_png_save(path: *const c_char, argb: *const u32, w: u32, h: u32) -> c_int;
     pub fn ir_free(p: *mut c_void);
     pub fn ir_exr_sample(rgb: *const c_float, w: u32, h: u32, dir: *const c_float, out_rgb: *mut c_float) -> c_int;
 }

@@ -238,3 +238,25 @@ def test_corrupted_files_never_crash(tmp_path, comp):
         except pta.InsplorayError:
             outcomes["error"] += 1
     assert outcomes["error"] > 50
+
+
+def test_png_save_round_trip(tmp_path):
+    """ir_png_save ("save image", a reference TODO): the resolved 0xAARRGGBB frame, bottom row first, as an RGB PNG read
+    back with an independent decoder (Pillow)."""
+    from PIL import Image
+    from path_tracer_amd import _capi
+    from path_tracer_amd.file_formats import save_png
+    rng = np.random.default_rng(3)
+    for (w, h) in ((1, 1), (7, 5), (640, 360)):
+        argb = rng.integers(0, 2 ** 32, size=w * h, dtype=np.uint64).astype(np.uint32)
+        path = tmp_path / f"f_{w}x{h}.png"
+        save_png(path, argb, w, h)
+        img = np.asarray(Image.open(path))
+        assert img.shape == (h, w, 3) and img.dtype == np.uint8
+        a = argb.reshape(h, w)[::-1]
+        want = np.stack([(a >> 16) & 0xFF, (a >> 8) & 0xFF, a & 0xFF], axis=-1).astype(np.uint8)
+        assert np.array_equal(img, want)
+    with pytest.raises(_capi.InsplorayError):
+        save_png(tmp_path / "no_such_dir" / "x.png", np.zeros(4, dtype=np.uint32), 2, 2)
+    with pytest.raises(ValueError):
+        save_png(tmp_path / "x.png", np.zeros(5, dtype=np.uint32), 2, 2)
