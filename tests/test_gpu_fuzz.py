@@ -21,9 +21,9 @@ def tracer(pta):
     rt.close()
 
 
-def _random_case(rng):
+def _random_case(rng, large=False):
     from path_tracer_amd import workloads as W
-    n = int(rng.choice([0, 1, 2, 3, 5, 17, 63, 64, 65, 130, 300]))
+    n = int(rng.choice([1000, 2047, 2048, 3000, 5000])) if large else int(rng.choice([0, 1, 2, 3, 5, 17, 63, 64, 65, 130, 300]))
     xyzr = np.zeros((n, 4), dtype=np.float32)
     xyzr[:, 0] = rng.uniform(-6, 6, n)
     xyzr[:, 1] = rng.uniform(-2, 4, n)
@@ -56,6 +56,10 @@ def _random_case(rng):
         sky = W.ExrImage(rng.uniform(0, 2, (3 * 2, 3)).astype(np.float32), 3, 2)
     scene = W.FlatScene(xyzr, mid, mats, default_sky_color=tuple(rng.uniform(0, 1, 3)), skybox=sky)
     w, h = int(rng.choice([1, 7, 31, 64, 65, 97])), int(rng.choice([1, 5, 33, 64, 70]))
+    if large:
+        w, h = min(w, 65), min(h, 33)
+        xyzr[:, 0] *= 3.0
+        xyzr[:, 2] *= 3.0
     from path_tracer_amd import PinholeCamera
     cam = PinholeCamera(tuple(rng.uniform(-1, 1, 3) + np.array([0, 0.5, 3.0])), tuple(rng.uniform(-0.4, 0.4, 3)),
                         float(rng.uniform(20, 60)), float(rng.uniform(30, 60)), [w, h])
@@ -69,11 +73,14 @@ def _random_case(rng):
     return scene, cam, w, h, cfg
 
 
-@pytest.mark.parametrize("case", range(200))
+@pytest.mark.parametrize("case", list(range(200)) + [f"large{i}" for i in range(40)])
 def test_random_configuration_bit_exact(pta, tracer, oracle, case):
     from path_tracer_amd import _capi
-    rng = np.random.default_rng(9000 + case)
-    scene, cam, w, h, cfg = _random_case(rng)
+    large = isinstance(case, str)
+    rng = np.random.default_rng(9000 + (int(case[5:]) + 5000 if large else case))
+    scene, cam, w, h, cfg = _random_case(rng, large)
+    if large and cfg["accel"] == "linear":
+        cfg["accel"] = "auto"
     tracer.set_active_camera(cam)
     tracer.set_integrator(bounces=cfg["bounces"], max_compulsory_bounces=cfg["rr"], seed=cfg["seed"])
     tracer.set_sample_block(cfg["block"])
