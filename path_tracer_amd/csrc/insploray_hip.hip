@@ -61,7 +61,7 @@ struct ir_context {
     uint32_t sky_w = 0, sky_h = 0;
     int sky_filter = IR_SKY_NEAREST;
     int sky_sampling = IR_SKY_SAMPLING_BSDF;
-    DeviceBuf d_sky_marginal, d_sky_cond, d_sky_pdf;
+    DeviceBuf d_sky_marginal, d_sky_cond, d_sky_pdf, d_sky_marginal_guide, d_sky_cond_guide;
     bool sky_tables_valid = false;
     int accel = IR_ACCEL_AUTO;
 
@@ -298,6 +298,8 @@ int ensure_sky_tables(ir_context* ctx) {
     IR_TRY(upload(ctx, ctx->d_sky_marginal, d.marginal.data(), d.marginal.size() * sizeof(float)));
     IR_TRY(upload(ctx, ctx->d_sky_cond, d.cond.data(), d.cond.size() * sizeof(float)));
     IR_TRY(upload(ctx, ctx->d_sky_pdf, d.pdf.data(), d.pdf.size() * sizeof(float)));
+    IR_TRY(upload(ctx, ctx->d_sky_marginal_guide, d.marginal_guide.data(), d.marginal_guide.size() * sizeof(uint32_t)));
+    IR_TRY(upload(ctx, ctx->d_sky_cond_guide, d.cond_guide.data(), d.cond_guide.size() * sizeof(uint32_t)));
     ctx->sky_tables_valid = true;
     return IR_OK;
 }
@@ -398,6 +400,7 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_wf_prim); release(ctx->d_wf_tileacc);
     release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index); release(ctx->d_bvh_scratch);
     release(ctx->d_sky_marginal); release(ctx->d_sky_cond); release(ctx->d_sky_pdf);
+    release(ctx->d_sky_marginal_guide); release(ctx->d_sky_cond_guide);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -623,6 +626,8 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
         a.sky_marginal = (const float*)ctx->d_sky_marginal.p;
         a.sky_cond = (const float*)ctx->d_sky_cond.p;
         a.sky_pdf = (const float*)ctx->d_sky_pdf.p;
+        a.sky_marginal_guide = (const uint32_t*)ctx->d_sky_marginal_guide.p;
+        a.sky_cond_guide = (const uint32_t*)ctx->d_sky_cond_guide.p;
     }
     a.bounces = ctx->bounces;
     a.rr_start = ctx->rr_start;

@@ -558,12 +558,29 @@ struct SkyTables {
     const float* marginal;  // h + 1
     const float* cond;      // h x (w + 1)
     const float* pdf;       // h x w, see sky_distribution.h
+    const uint32_t* marginal_guide;  // h + 1
+    const uint32_t* cond_guide;      // h x (w + 1)
 };
 constexpr uint32_t kSkyDrawBase = 0x40000000u;  // draw indices of the sky strategy: kSkyDrawBase + 2 * bounce + {0, 1}
 
 // largest i in [0, n) with cdf[i] <= x (cdf[0] == 0 <= x < 1 == cdf[n])
 PT_DEV uint32_t cdf_find(const float* __restrict__ cdf, uint32_t n, float x) {
     uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+// The same index, found in a range narrowed by the guide (sky_distribution.h): with k = floor(x * n) the answer lies in
+// [guide[k - 1], guide[k + 2]] — one bucket of slack on either side covers the rounding of x * n and of k / n — which for
+// all but the darkest parts of an image is two or three entries instead of n.
+PT_DEV uint32_t cdf_find_guided(const float* __restrict__ cdf, const uint32_t* __restrict__ guide, uint32_t n, float x) {
+    uint32_t k = (uint32_t)(x * (float)n);
+    k = k < n ? k : n - 1;
+    uint32_t lo = guide[k > 0 ? k - 1 : 0];
+    const uint32_t k2 = k + 2 < n ? k + 2 : n;
+    uint32_t hi = guide[k2] + 1;  // cdf[hi] > x (hi <= n, cdf[n] == 1)
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (cdf[mid] <= x) lo = mid; else hi = mid;
@@ -594,10 +611,10 @@ PT_DEV float sky_density(const SkyTables& t, size_t texel, float sin_polar) {
 // Direction drawn from the sky distribution: texel (ix, iy), a point inside it, unit direction ws, sin of its polar angle.
 PT_DEV void sky_sample(const SkyTables& t, uint32_t sw, uint32_t sh, float x1, float x2, uint32_t& ix, uint32_t& iy, f3& ws,
                        float& sin_polar) {
-    iy = cdf_find(t.marginal, sh, x1);
+    iy = cdf_find_guided(t.marginal, t.marginal_guide, sh, x1);
     const float fy = cdf_frac(x1, t.marginal[iy], t.marginal[iy + 1]);
     const float* row = t.cond + (size_t)iy * (sw + 1);
-    ix = cdf_find(row, sw, x2);
+    ix = cdf_find_guided(row, t.cond_guide + (size_t)iy * (sw + 1), sw, x2);
     const float fx = cdf_frac(x2, row[ix], row[ix + 1]);
     const float u = ((float)ix + fx) / (float)sw;
     const float v = ((float)iy + fy) / (float)sh;

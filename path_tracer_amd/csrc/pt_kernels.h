@@ -32,6 +32,8 @@ struct RenderArgs {
     const float* sky_marginal;
     const float* sky_cond;
     const float* sky_pdf;
+    const uint32_t* sky_marginal_guide;
+    const uint32_t* sky_cond_guide;
 
     uint32_t bounces, rr_start;
     uint32_t seed_lo, seed_hi;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
             int idx = idx0;
             f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
             if (STATS) { n_traces = 1; n_disc = disc0; n_hits = 1; }
-            const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf};
+            const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
 
             while (s < spp) {
                 // ---- shade the hit of bounce b (integrator.rs:50-81)
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
     bool shadow = false;
     f3 wi_next = mk3(0, 0, 0), sky_term = mk3(0, 0, 0);
     float ray_density = 0.0f;
-    const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf};
+    const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
 
     for (;;) {
         const bool waiting = !traversing && s < spp;

@@ -14,6 +14,16 @@ double texel_weight(const float* t, bool uniform) {
     return (lum > 0.0 && !std::isinf(lum)) ? lum : 0.0;
 }
 
+// guide[k] = largest i in [0, n) with cdf[i] <= (float)k / (float)n, for k = 0 .. n (cdf[0] == 0, non-decreasing)
+void build_guide(const float* cdf, uint32_t n, uint32_t* guide) {
+    uint32_t i = 0;
+    for (uint32_t k = 0; k <= n; ++k) {
+        const float x = (float)k / (float)n;
+        while (i + 1 < n && cdf[i + 1] <= x) ++i;
+        guide[k] = i;
+    }
+}
+
 }  // namespace
 
 void build_sky_distribution(const float* rgba, uint32_t w, uint32_t h, SkyDistribution& out) {
@@ -60,6 +70,10 @@ void build_sky_distribution(const float* rgba, uint32_t w, uint32_t h, SkyDistri
         const float* c = &out.cond[stride * y];
         for (uint32_t x = 0; x < w; ++x) out.pdf[(size_t)y * w + x] = (float)((p_row * ((double)c[x + 1] - (double)c[x])) * per_area);
     }
+    out.marginal_guide.assign((size_t)h + 1, 0u);
+    build_guide(out.marginal.data(), h, out.marginal_guide.data());
+    out.cond_guide.assign(stride * h, 0u);
+    for (uint32_t y = 0; y < h; ++y) build_guide(&out.cond[stride * y], w, &out.cond_guide[stride * y]);
 }
 
 }  // namespace pt

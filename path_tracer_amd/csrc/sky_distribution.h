@@ -14,6 +14,11 @@ struct SkyDistribution {
     std::vector<float> marginal;  // h + 1: CDF over rows, [0] = 0, [h] = 1
     std::vector<float> cond;      // h x (w + 1): CDF over the columns of each row
     std::vector<float> pdf;       // h x w: probability of the texel x w h / (2 pi^2); / sin(theta) = density per solid angle
+    // Search guides (pt_device.h cdf_find_guided): entry k of an n-entry CDF's guide = largest i in [0, n) with
+    // cdf[i] <= (float)k / (float)n, k = 0 .. n.  They narrow the binary search to a few entries; the index found is
+    // the one the plain search finds.
+    std::vector<uint32_t> marginal_guide;  // h + 1
+    std::vector<uint32_t> cond_guide;      // h x (w + 1)
 };
 
 // rgba: w x h texels padded to 4 floats (the device layout of ir_set_skybox), row 0 = zenith.
