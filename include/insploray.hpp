@@ -17,6 +17,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "insploray_hip.h"
@@ -219,6 +220,16 @@ public:
     // ---- extensions the reference does not have (each one call into the C ABI)
     void set_sky_filter(int filter) { check(ir_set_sky_filter(ctx_, filter)); }              // IR_SKY_NEAREST == exr.rs:20-23
     void set_accel(int accel) { check(ir_set_accel(ctx_, accel)); }                          // IR_ACCEL_AUTO / LINEAR / LBVH
+    void set_accel_build(int build) { check(ir_set_accel_build(ctx_, build)); }              // IR_BUILD_AUTO / HOST / DEVICE / REFIT
+    void set_sky_sampling(int mode) { check(ir_set_sky_sampling(ctx_, mode)); }              // IR_SKY_SAMPLING_BSDF == integrator.rs:64-70,84-89
+    void set_schedule(int schedule, uint32_t max_paths = 0) { check(ir_set_schedule(ctx_, schedule, max_paths)); }
+    // get_output without the copy: the borrowed slice of renderer.rs:164-169, valid until the next call / resize
+    std::pair<const uint32_t*, size_t> map_output() {
+        const uint32_t* p = nullptr;
+        size_t n = 0;
+        check(ir_map_output_argb(ctx_, &p, &n));
+        return {p, n};
+    }
     void set_sample_block(uint32_t samples) { check(ir_set_sample_block(ctx_, samples)); }
     void set_partition(int mode, uint32_t rank, uint32_t world) { check(ir_set_partition(ctx_, mode, rank, world)); }
     uint32_t samples_accumulated() const { return ir_samples_accumulated(ctx_); }
