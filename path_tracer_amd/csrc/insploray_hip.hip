@@ -425,14 +425,19 @@ int ir_set_spheres(ir_context* ctx, const float* spheres_xyzr, const int32_t* ma
         return fail(ctx, IR_ELIMIT, "ir_set_spheres: %u spheres exceed the %u the linear scan stages in LDS (use IR_ACCEL_AUTO/LBVH)", n,
                     pt::kMaxLdsSpheres);
     IR_TRY(use_device(ctx));
-    if (n == ctx->n_spheres && (n == 0 || (memcmp(ctx->h_spheres.data(), spheres_xyzr, (size_t)n * 16) == 0 &&
-                                           memcmp(ctx->h_matid.data(), material_id, (size_t)n * 4) == 0)))
-        return IR_OK;  // unchanged scene (the facade re-sends it on every render): keep device tables and the LBVH
+    // The facade re-sends the scene on every render: what did not change keeps its device tables.  The shading table
+    // depends on the material ids only, so moving spheres (the editor's common edit) keeps it; the LBVH depends on the
+    // geometry only.
+    const bool same_ids = n == ctx->n_spheres && (n == 0 || memcmp(ctx->h_matid.data(), material_id, (size_t)n * 4) == 0);
+    const bool same_geometry = n == ctx->n_spheres && (n == 0 || memcmp(ctx->h_spheres.data(), spheres_xyzr, (size_t)n * 16) == 0);
+    ctx->n_spheres = n;
+    if (!same_ids) {
+        ctx->h_matid.assign(material_id, material_id + n);
+        ctx->shade_dirty = true;
+    }
+    if (same_geometry) return IR_OK;
     ctx->bvh_valid = false;
     ctx->h_spheres.assign(spheres_xyzr, spheres_xyzr + (size_t)n * 4);
-    ctx->h_matid.assign(material_id, material_id + n);
-    ctx->n_spheres = n;
-    ctx->shade_dirty = true;
     IR_TRY(upload(ctx, ctx->d_spheres, ctx->h_spheres.data(), (size_t)n * 4 * sizeof(float)));
     return IR_OK;
 }
@@ -440,6 +445,8 @@ int ir_set_spheres(ir_context* ctx, const float* spheres_xyzr, const int32_t* ma
 int ir_set_materials(ir_context* ctx, const float* materials9, uint32_t n) {
     if (!ctx) return IR_EINVAL;
     if (n && !materials9) return fail(ctx, IR_EINVAL, "ir_set_materials: NULL array with n=%u", n);
+    if (ctx->h_materials.size() == (size_t)n * 9 && (n == 0 || memcmp(ctx->h_materials.data(), materials9, (size_t)n * 36) == 0))
+        return IR_OK;  // unchanged (re-sent on every render)
     ctx->h_materials.assign(materials9, materials9 + (size_t)n * 9);
     ctx->shade_dirty = true;
     return IR_OK;
