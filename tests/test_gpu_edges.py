@@ -162,3 +162,40 @@ def test_mapped_output_equals_copied_output(pta, tracer):
         assert (mapped >> 24 == 0xBA).all()  # alpha of a rendered pixel: Reinhard(1) ** (1/2.2) * 255 truncated
     with pytest.raises(pta.InsplorayError):
         _capi.check(tracer._ctx, _capi.lib.ir_map_output_argb(tracer._ctx, None, None))
+
+
+def test_partial_scene_edits_keep_only_what_they_may(pta, tracer, oracle):
+    """ir_set_spheres / ir_set_materials keep the device tables of what did not change (moving spheres keeps the shading
+    table, recolouring keeps the LBVH): every step of an edit sequence still renders the oracle's frame."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = 96, 54, 3
+    base = W.scene_s2(n=400, skybox=None)
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    tracer.set_integrator(bounces=6, max_compulsory_bounces=2, seed=SEED)
+    xyzr, mid, mats = base.xyzr.copy(), base.material_id.copy(), base.materials9.copy()
+    steps = []
+    steps.append((xyzr.copy(), mid.copy(), mats.copy()))                       # the scene
+    xyzr[1:, 0] += np.float32(0.3)
+    steps.append((xyzr.copy(), mid.copy(), mats.copy()))                       # geometry only
+    mid = ((mid + 7) % mats.shape[0]).astype(np.int32)
+    steps.append((xyzr.copy(), mid.copy(), mats.copy()))                       # material ids only
+    mats[:, :3] = mats[::-1, :3]
+    steps.append((xyzr.copy(), mid.copy(), mats.copy()))                       # materials only
+    steps.append((xyzr.copy(), mid.copy(), mats.copy()))                       # nothing
+    steps.append((xyzr[:300].copy(), mid[:300].copy(), mats.copy()))           # fewer spheres
+    frames = []
+    for accel in (_capi.IR_ACCEL_LBVH, _capi.IR_ACCEL_LINEAR):
+        tracer.set_accel(accel)
+        try:
+            for (x, m, t) in steps:
+                scene = W.FlatScene(x, m, t, default_sky_color=(0.6, 0.7, 0.9), skybox=None)
+                tracer.render(scene, w, h, False, spp=spp)
+                s, c = tracer.get_radiance()
+                os_, oc, _, _ = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=6, rr_start=2, seed=SEED, math_mode=1)
+                assert np.array_equal(s.view(np.uint32), os_.view(np.uint32))
+                frames.append(s.copy())
+        finally:
+            tracer.set_accel(_capi.IR_ACCEL_AUTO)
+    assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[1], frames[2]) and not np.array_equal(frames[2], frames[3])
+    assert np.array_equal(frames[3], frames[4])
