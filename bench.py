@@ -8,8 +8,11 @@ bounce 2, seed 0x0123456789ABCDEF) starting from a reset accumulator.  Inputs (s
 the device before the timed region; the timed region contains the integrator launches (and, for N > 1, the RCCL
 reduce of the partial radiance buffers to rank 0 — the path's one exchange step).
 
-N > 1 (launched by torch.distributed.run, one process per GPU): sample-range partition, every rank renders the whole
-frame for its own 1024 sample indices (weak scaling: per-GPU work fixed), partial sums are reduced over RCCL.
+N > 1 (one process per GPU, launched by torch.distributed.run — or by this script itself when it is started plainly as
+`python bench.py --gpus N`: the parent touches no GPU, spawns the ranks, relays their output and exit code): sample-range
+partition, every rank renders the whole frame for its own 1024 sample indices (weak scaling: per-GPU work fixed); the
+partial films are combined on rank 0 by the library's own RCCL step (ir_combine_async: snapshot, grouped reduce on a
+stream of its own, overlapped with the next step's render); `exchange` in the JSON line reports its device time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,6 +28,7 @@ if ROOT not in sys.path:
 
 W, H, SPP, BOUNCES, RR = 1920, 1080, 1024, 8, 2
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
+NOFMA_CEILING_TFLOPS = 78.6    # the same issue rate with one flop per lane-op (mul/add, no FMA contraction)
 
 
 def flops_per_sample(st, ast=None):
@@ -41,11 +45,34 @@ def flops_per_sample(st, ast=None):
     return total / samples
 
 
+def host_cpu():
+    """(threads this process may use, CPUs the machine shows, model string).  On a shared box the usable share is the
+    affinity mask capped by OMP_NUM_THREADS (the GPU boxes export their per-GPU CPU share that way)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        usable = min(usable, int(share))
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return max(1, usable), os.cpu_count() or 1, model
+
+
 def cpu_baseline(scene, cam_params, budget_s=12.0, max_spp=64):
     """The oracle (C++ restatement of the reference CPU path; the Rust reference cannot be built here) timed on this
-    box's host cores on a bounded sample of the same workload: full 1920x1080 frame, same scene/seed/depth, fewer spp."""
+    box's host cores on a bounded sample of the same workload: full 1920x1080 frame, same scene/seed/depth, fewer spp.
+    Every core this process may use, plus the reference-shaped figure (4 worker threads, renderer.rs:45)."""
     from tests import oracle_lib as O
-    cores = min(16, os.cpu_count() or 1)
+    cores, visible, model = host_cpu()
     oc = O.OracleCamera(*cam_params, W, H)
     # calibrate with 1 spp, then size the sample to about budget_s seconds
     _, _, t1, _ = O.render(oc, scene, 1, bounces=BOUNCES, rr_start=RR, threads=cores)
@@ -57,10 +84,30 @@ def cpu_baseline(scene, cam_params, budget_s=12.0, max_spp=64):
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"1920x1080, {spp} spp of the workload's (same scene/seed/depth 8), 64x64 tiles on {cores} threads; "
+        "sample": f"1920x1080, {spp} spp of the workload's (same scene/seed/depth {BOUNCES}), 64x64 tiles on {cores} threads "
+                  f"(every core this process may use: affinity mask capped by the box's OMP_NUM_THREADS share); "
                   f"C++ restatement of the reference integrator (linear scan), libm math",
+        "cpu_model": model,
+        "host_cpus_visible": visible,
         "reference_shaped_4_threads_Msamples_s": W * H * max(1, spp // 4) / t4 / 1e6,
     }
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` started plainly: spawn the N ranks with torch.distributed.run from this process, which
+    has made no GPU call (and makes none), relay their output and return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
@@ -85,6 +132,11 @@ def main():
     ap.add_argument("--sky-sampling", choices=["bsdf", "mis"], default="bsdf",
                     help="bsdf = the reference's estimator (the metric's); mis = sky importance sampling (extension: one more "
                          "trace per bounce, far lower variance under a sun-dominated sky; see tools/sky_sampling_convergence.py)")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
+                    help="N > 1 only. native (default): the library's RCCL step (ir_comm_init / ir_combine_async), overlapped "
+                         "with the next render; falls back to torch if RCCL cannot be initialised. torch: torch.distributed "
+                         "reduce of the accumulator tensors on the render stream.")
+    ap.add_argument("--sample-block", type=int, default=None, help="ir_set_sample_block (0 = auto); the metric uses the default 128")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a box with ONE GPU: every rank uses device 0 and the exchange step goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
@@ -92,6 +144,9 @@ def main():
     global BOUNCES
     if args.bounces is not None:
         BOUNCES = args.bounces
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves (this parent never touches the GPU)
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     import numpy as np
     import torch
@@ -101,8 +156,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.rehearse_one_gpu:
@@ -146,22 +200,51 @@ def main():
                      "wavefront": _capi.IR_SCHEDULE_WAVEFRONT}[args.schedule])
     rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
     rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
-    # accumulator in torch-owned device memory so that RCCL can reduce it in place
-    sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    counts = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-    _capi.check(rt._ctx, _capi.lib.ir_bind_accumulator(rt._ctx, sums.data_ptr(), counts.data_ptr(), W, H))
-    # launch on torch's current stream: the RCCL reduce (ordered against that stream by torch.distributed) and the
-    # next step's accumulator reset are then ordered by the stream, not by luck
-    _capi.check(rt._ctx, _capi.lib.ir_set_stream(rt._ctx, torch.cuda.current_stream().cuda_stream))
+    if args.sample_block is not None:
+        rt.set_sample_block(args.sample_block)
     partition = args.partition or ("tiles" if args.workload == "c4" else "samples")
     if world > 1:
         rt.set_partition(_capi.IR_PARTITION_TILES if partition == "tiles" else _capi.IR_PARTITION_SAMPLES, rank, world)
     # samples: every rank adds `spp` samples to every pixel (work grows with N); tiles: the frame is split (work fixed)
     work_ranks = world if partition == "samples" else 1
 
+    # ---- the exchange step of N > 1
+    exchange, native, native_error = "none", None, None
+    if world > 1 and args.rehearse_one_gpu:
+        exchange = "gloo on host copies (one-GPU rehearsal)"
+    elif world > 1 and args.exchange == "native":
+        from path_tracer_amd.distributed import NativeExchange
+        try:
+            native = NativeExchange(rt, rank, world)
+        except Exception as e:  # RCCL missing or refusing: say so and use torch's
+            native_error = repr(e)
+        ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if native is not None:
+                native.close()
+            native = None
+        exchange = "ir_combine_async (library RCCL step, overlapped with the next render)" if native else \
+                   "torch.distributed reduce (native RCCL init failed: %s)" % native_error
+    elif world > 1:
+        exchange = "torch.distributed reduce on the render stream"
+    sums = counts = None
+    if native is None:
+        # accumulator in torch-owned device memory so that torch's RCCL can reduce it in place, launches on torch's
+        # current stream so that the reduce and the next step's accumulator reset are ordered by the stream
+        sums = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        counts = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        _capi.check(rt._ctx, _capi.lib.ir_bind_accumulator(rt._ctx, sums.data_ptr(), counts.data_ptr(), W, H))
+        _capi.check(rt._ctx, _capi.lib.ir_set_stream(rt._ctx, torch.cuda.current_stream().cuda_stream))
+
     kernel_ms = []
 
     def step():
+        if native is not None:
+            # nothing here blocks the host: render k+1 is enqueued behind the snapshot of render k and overlaps exchange k
+            rt.render(scene, W, H, False, spp=spp, blocking=False)
+            native.combine_async(0)
+            return
         rt.render(scene, W, H, False, spp=spp)  # blocks until the launches are done
         kernel_ms.append(rt.last_kernel_ms())
         if world > 1 and args.rehearse_one_gpu:
@@ -176,6 +259,9 @@ def main():
             dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
+        if native is not None:
+            rt.synchronize()
+            native.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -183,8 +269,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kernel_ms.clear()
     fence()
+    kernel_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -194,13 +280,26 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    exchange_info = None
+    if world > 1:
+        exchange_info = {"how": exchange}
+        if native is not None:
+            kernel_ms.append(rt.last_kernel_ms())  # the last step's launches (the steps are identical)
+            exchange_info["last_exchange_ms"] = native.last_ms()
+            exchange_info["bytes_per_rank"] = (int(_capi.lib.ir_tile_payload_bytes(W, H, rank, world)) if partition == "tiles"
+                                               else W * H * 20)
+            if rank == 0:
+                # the combined film must hold every rank's samples
+                _, cc = rt.get_radiance()
+                want = spp * (world if partition == "samples" else 1)
+                exchange_info["verified_counts"] = bool((cc == want).all())
 
     # ---- roofline of the dominant kernel (render_kernel), rank 0 only
     out = None
     if rank == 0:
         ms = [m for m, _ in kernel_ms]
         launches = sum(n for _, n in kernel_ms)
-        avg_launch_ms = sum(ms) / max(launches, 1)
+        avg_launch_ms = sum(ms) / max(launches, 1)  # HIP events around the launches, on the stream they run on
         # algorithmic flops per sample from the kernel's own counters (untimed extra render, same workload)
         if world > 1:
             rt.set_partition(_capi.IR_PARTITION_NONE, 0, 1)
@@ -214,12 +313,20 @@ def main():
         samples_per_launch = W * H * spp / max(1, kernel_ms[0][1]) / (world if partition == "tiles" else 1)
         achieved = samples_per_launch * F / (avg_launch_ms * 1e-3) / 1e12
         total_samples = work_ranks * W * H * spp * args.steps
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same launch (C2 at 1024 spp only)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if args.workload == "c2" and spp == SPP and not lbvh and os.path.exists(tpath):
+        # Counter-derived figures of this same launch (C2 at 1024 spp) from the round's committed rocprofv3 PMC passes
+        # (profiles/r2_pmc_roofline.json, written by tools/pmc_summary.py --json from tools/gpu_profile.sh's passes over
+        # the tree that is benchmarked): HBM-side bytes, lane utilisation, executed FP instruction mix.  Rates are formed
+        # with the launch duration measured live above.
+        traffic = lane_util = executed_tf = pmc_source = None
+        tpath = os.path.join(ROOT, "profiles", "r2_pmc_roofline.json")
+        if args.workload == "c2" and spp == SPP and not lbvh and BOUNCES == 8 and os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
+                pmc = json.load(f)
+            traffic = pmc.get("traffic_bytes_per_launch")
+            lane_util = pmc.get("lane_utilisation")
+            if pmc.get("executed_flop_per_launch"):
+                executed_tf = pmc["executed_flop_per_launch"] / (avg_launch_ms * 1e-3) / 1e12
+            pmc_source = pmc.get("source")
         out = {
             "metric": "Msamples/sec (path samples, max depth 8) at 1920x1080",
             "value": total_samples / elapsed / 1e6,
@@ -237,7 +344,7 @@ def main():
                 "workload": f"{wl_name}, bounces {BOUNCES}, rr_start {RR}, "
                             + (f"LBVH ({info['nodes']} nodes, depth {info['depth']})" if lbvh else "linear LDS scan"),
                 "partition": "none" if world == 1 else (f"sample-range x{world}" if partition == "samples" else
-                                                       f"64x64 tiles round-robin x{world}") + " + RCCL reduce(sum) to rank 0",
+                                                       f"64x64 tiles round-robin x{world}") + (" + RCCL reduce(sum) to rank 0" if partition == "samples" or native is None else " + RCCL gather of owned tiles to rank 0"),
                 "seed": hex(Wk.RNG_SEED),
                 "sky_sampling": args.sky_sampling,
             },
@@ -248,8 +355,13 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_traffic.json); algorithmic: "
-                                "40 B/pixel accumulator = 83 MB + 16 B per escaping path from the L2/MALL-resident sky",
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, separate --pmc passes); algorithmic: 40 B/pixel "
+                                "accumulator = 83 MB + 16 B per block sum and pixel + 16 B per escaping path from the "
+                                "L2/MALL-resident sky",
+                "frac_of_nofma_ceiling": achieved / NOFMA_CEILING_TFLOPS,
+                "executed_fp_tflops": executed_tf,
+                "lane_utilisation": lane_util,
+                "pmc_source": pmc_source,
                 "kernel": "render_kernel<%s, false>" % ("lbvh" if lbvh else "linear"),
                 "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": kernel_ms[0][1],
@@ -258,9 +370,13 @@ def main():
                 "brute_force_equivalent_flops_per_sample": flops_per_sample(st, None),
                 "note": "FP32 vector peak 157.3 TF assumes FMA; this path is bit-exact (no FMA contraction), so its "
                         "issue ceiling is 78.6 TF (one flop per lane-op); algorithmic flops count the primary ray "
-                        "per sample although the kernel shares it across the samples of a pixel",
+                        "per sample although the kernel shares it across the samples of a pixel; executed_fp_tflops = "
+                        "FP32 ops the kernel actually issued (ADD + MUL + TRANS + 2 FMA wave-instructions x 64 lanes x "
+                        "lane utilisation, from the PMC passes) / the live launch time",
             },
         }
+        if exchange_info is not None:
+            out["exchange"] = exchange_info
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, (cam.position, cam.rotation, cam.focal_length, cam.sensor_size),
                                                max_spp=64 if args.workload == "c2" else 1)

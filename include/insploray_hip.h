@@ -13,7 +13,8 @@
  *   - every function returns 0 on success, a negative IR_E* code on failure, never aborts;
  *     ir_last_error(ctx) gives the message of the last failure on that context;
  *   - a context is bound to ONE GPU (one process per GPU; multi-GPU = one context per rank, partial
- *     radiance buffers combined by the caller with RCCL, see ir_set_partition / ir_bind_accumulator);
+ *     radiance buffers combined on a root rank by ir_combine over RCCL, see ir_set_partition / ir_comm_init;
+ *     a caller with its own transport can use ir_bind_accumulator or ir_pack_owned_tiles instead);
  *   - a context is single-caller (not re-entrant), like RayTracer which is `&mut self` everywhere;
  *   - there is no CPU fallback: without a HIP device ir_create fails.
  */
@@ -45,6 +46,8 @@ enum { IR_PARTITION_NONE = 0, IR_PARTITION_TILES = 1, IR_PARTITION_SAMPLES = 2 }
 enum { IR_ACCEL_AUTO = 0, IR_ACCEL_LINEAR = 1, IR_ACCEL_LBVH = 2 };
 enum { IR_BUILD_AUTO = 0, IR_BUILD_HOST = 1, IR_BUILD_DEVICE = 2, IR_BUILD_REFIT = 3 };
 enum { IR_SCHEDULE_AUTO = 0, IR_SCHEDULE_REGENERATION = 1, IR_SCHEDULE_WAVEFRONT = 2 };
+enum { IR_SAMPLE_BLOCK_AUTO = 0 };  /* ir_set_sample_block */
+#define IR_COMM_ID_BYTES 128        /* sizeof(ncclUniqueId), ir_comm_unique_id / ir_comm_init */
 
 /* ABI version of this header (bumped on incompatible change). */
 uint32_t ir_abi_version(void);
@@ -152,8 +155,14 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
  * samples_per_block samples; each block is summed from zero in sample order (the tile accumulator) and the block
  * sums are merged into the accumulator in block order.  Blocks are independent until the merge, which is what lets
  * one call fill the GPU.  On a zeroed accumulator a call with spp <= samples_per_block is bit-identical to spp
- * successive reference-style 1-sample calls. */
+ * successive reference-style 1-sample calls.
+ * IR_SAMPLE_BLOCK_AUTO (0): 128, halved (not below 8) until the launch has at least 8192 workgroups, i.e. the blocks
+ * shrink for small frames and low sample counts so that the 256 CUs stay full (the reference's own headless case, 800x450
+ * at 64 spp, is one block on 1407 workgroups otherwise).  A pure function of the workgroups per block — 16 per 64x64 tile
+ * this rank owns — and spp; ir_get_sample_block returns what a render of that shape would use, so that a caller (or a
+ * checker) can reproduce the order of the sums. */
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);
+int ir_get_sample_block(const ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t* out_samples_per_block);
 
 /* How the integrator is scheduled on the GPU (results are identical bit for bit, only speed differs):
  *   IR_SCHEDULE_REGENERATION : one kernel; a lane owns a pixel and runs its samples in order, restarting at the
@@ -172,8 +181,45 @@ int ir_set_schedule(ir_context* ctx, int schedule, uint32_t max_paths);
  *   IR_PARTITION_SAMPLES: every rank renders all pixels; ir_render(spp) renders the sample indices
  *                         [base + rank*spp, base + (rank+1)*spp) where base = world * (samples already
  *                         accumulated per rank), i.e. spp is PER RANK.
- * Partial buffers are summed by the caller (RCCL reduce of ir_device_radiance / ir_device_counts). */
+ * Partial buffers are combined on a root rank by ir_combine (below), or by the caller (a reduce of
+ * ir_device_radiance / ir_device_counts, or a gather of ir_pack_owned_tiles payloads). */
 int ir_set_partition(ir_context* ctx, int mode, uint32_t rank, uint32_t world);
+
+/* -------------------------------------------------------------------------------------------------
+ * Exchange step.  Replaces the merge loop of RayTracer::render (renderer.rs:152-159), where the main thread receives
+ * each worker's TileAccumulator over a channel and adds it into the frame (full_buffer.rs:107-125): here a worker is a
+ * GPU, the channel is RCCL over xGMI, and the "main thread" is the root rank.  One process per GPU, one context each.
+ *   ir_comm_unique_id : rank 0 creates the rendezvous id (ncclGetUniqueId) and hands the IR_COMM_ID_BYTES to every
+ *                       rank by any means the host has (a pipe, a file, MPI, torch.distributed ...);
+ *   ir_comm_init      : collective; every rank joins with its rank and the world size (ncclCommInitRank on the
+ *                       context's device).  RCCL is loaded at run time (librccl.so.1); IR_EDEVICE if it is absent;
+ *   ir_combine        : collective, blocking.  IR_PARTITION_SAMPLES: one grouped ncclReduce(sum) of the float4 sums and
+ *                       the u32 counts.  IR_PARTITION_TILES: tiles are disjoint, so merging is a gather: every rank
+ *                       sends its owned tiles as one packed payload (20 B per pixel, 1/world of the frame), the root
+ *                       unpacks them; bit-identical to a one-GPU render.  The combined film lives in a buffer of its own
+ *                       on the root; every rank's own accumulator is left as it was, so progressive rendering can go on.
+ *                       On the root, ir_get_output_argb / ir_map_output_argb / ir_get_radiance show the combined film
+ *                       until that context's next render;
+ *   ir_combine_async  : the same, enqueued: the exchange reads a snapshot of the accumulator taken on the render stream
+ *   ir_combine_wait     and runs on a stream of its own, so the next ir_render overlaps it; ir_combine_wait blocks until
+ *                       the last exchange has finished (and reports an asynchronous RCCL error, if any);
+ *   ir_last_combine_ms: device time of the last exchange (its own stream, start to end), waiting for peers included.
+ * ------------------------------------------------------------------------------------------------- */
+int ir_comm_unique_id(uint8_t out_id[IR_COMM_ID_BYTES]);
+int ir_comm_init(ir_context* ctx, const uint8_t id[IR_COMM_ID_BYTES], uint32_t rank, uint32_t world);
+int ir_comm_destroy(ir_context* ctx);
+int ir_combine(ir_context* ctx, uint32_t root);
+int ir_combine_async(ir_context* ctx, uint32_t root);
+int ir_combine_wait(ir_context* ctx);
+double ir_last_combine_ms(const ir_context* ctx);
+/* The transport-independent halves of the tile gather, for hosts that move bytes themselves.  A payload holds the
+ * 64x64 tiles rank r owns under IR_PARTITION_TILES (tile t iff t % world == r, in increasing t), each tile row-major,
+ * pixels outside the frame zero: all float4 sums first, then all u32 counts; ir_tile_payload_bytes gives its size.
+ * ir_pack_owned_tiles packs this context's accumulator (its own rank / world; one rank owning everything without a
+ * tile partition) into device memory; ir_unpack_tiles writes rank r's payload into this context's accumulator. */
+size_t ir_tile_payload_bytes(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
+int ir_pack_owned_tiles(ir_context* ctx, void* d_payload, size_t bytes);
+int ir_unpack_tiles(ir_context* ctx, const void* d_payload, size_t bytes, uint32_t rank, uint32_t world);
 
 /* -------------------------------------------------------------------------------------------------
  * Render.  Replaces RayTracer::render(scene, width, height, acc) (renderer.rs:95-162):

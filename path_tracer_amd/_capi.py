@@ -26,6 +26,8 @@ IR_ACCEL_AUTO, IR_ACCEL_LINEAR, IR_ACCEL_LBVH = 0, 1, 2
 IR_BUILD_AUTO, IR_BUILD_HOST, IR_BUILD_DEVICE, IR_BUILD_REFIT = 0, 1, 2, 3
 IR_SKY_SAMPLING_BSDF, IR_SKY_SAMPLING_MIS = 0, 1
 IR_SCHEDULE_AUTO, IR_SCHEDULE_REGENERATION, IR_SCHEDULE_WAVEFRONT = 0, 1, 2
+IR_SAMPLE_BLOCK_AUTO = 0
+IR_COMM_ID_BYTES = 128
 
 c_float_p = C.POINTER(C.c_float)
 c_i32_p = C.POINTER(C.c_int32)
@@ -62,7 +64,18 @@ PROTOTYPES = {
     "ir_set_integrator": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "ir_set_schedule": (C.c_int, [ctx_p, C.c_int, C.c_uint32]),
     "ir_set_sample_block": (C.c_int, [ctx_p, C.c_uint32]),
+    "ir_get_sample_block": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, c_u32_p]),
     "ir_set_partition": (C.c_int, [ctx_p, C.c_int, C.c_uint32, C.c_uint32]),
+    "ir_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ir_comm_init": (C.c_int, [ctx_p, C.c_char_p, C.c_uint32, C.c_uint32]),
+    "ir_comm_destroy": (C.c_int, [ctx_p]),
+    "ir_combine": (C.c_int, [ctx_p, C.c_uint32]),
+    "ir_combine_async": (C.c_int, [ctx_p, C.c_uint32]),
+    "ir_combine_wait": (C.c_int, [ctx_p]),
+    "ir_last_combine_ms": (C.c_double, [ctx_p]),
+    "ir_tile_payload_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "ir_pack_owned_tiles": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t]),
+    "ir_unpack_tiles": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]),
     "ir_render": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "ir_render_async": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "ir_synchronize": (C.c_int, [ctx_p]),

@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -388,6 +391,8 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
         int64_t chunks;
         if (p.tiled) {
             if (p.tile_w == 0 || p.tile_h == 0) return set_err(IR_EIO, "tiled EXR part without a tile description");
+            // a tile edge beyond the largest supported image edge (or with the sign bit set) cannot address the data window
+            if (p.tile_w > 65536u || p.tile_h > 65536u) return set_err(IR_ELIMIT, "EXR tile size larger than 65536");
             if (multipart && p.chunk_count > 0) {
                 chunks = p.chunk_count;
             } else {
@@ -400,6 +405,8 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
             chunks = (h + lpb - 1) / lpb;
             if (multipart && p.chunk_count > 0) chunks = p.chunk_count;
         }
+        // every chunk has an 8-byte table entry: a count the rest of the file cannot hold is a corrupt header
+        if (chunks <= 0 || (uint64_t)chunks > (uint64_t)(n - r.pos) / 8) return set_err(IR_EIO, "truncated EXR offset table");
         tables[pi].resize((size_t)chunks);
         for (auto& o : tables[pi]) o = r.u64();
         if (!r.ok) return set_err(IR_EIO, "truncated EXR offset table");
@@ -430,16 +437,14 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
     }
     float* img = (float*)std::malloc((size_t)W * H * 3 * sizeof(float));
     if (!img) return set_err(IR_ENOMEM, "out of memory for the EXR image");
+    std::unique_ptr<float, void (*)(void*)> img_owner(img, std::free);  // released to the caller on success only
     std::memset(img, 0, (size_t)W * H * 3 * sizeof(float));
     std::vector<uint8_t> raw, scratch;
     std::vector<int> types;
     for (const Channel& c : p.channels) types.push_back(c.type);
     const int lpb = p.tiled ? 0 : lines_per_block(p.compression);
 
-    auto bail = [&](const char* m) {
-        std::free(img);
-        return set_err(IR_EIO, m);
-    };
+    auto bail = [&](const char* m) { return set_err(IR_EIO, m); };
     for (uint64_t off : tables[sel]) {
         Reader c{bytes, n, (size_t)off};
         if (off >= n) return bail("EXR chunk offset outside the file");
@@ -452,11 +457,13 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
             const int32_t tx = c.i32(), ty = c.i32(), lx = c.i32(), ly = c.i32();
             if (!c.ok) return bail("truncated EXR tile header");
             if (lx != 0 || ly != 0) continue;  // only the full-resolution level
-            x0 = tx * (int)p.tile_w;
-            y0 = ty * (int)p.tile_h;
-            if (tx < 0 || ty < 0 || x0 >= (int)W || y0 >= (int)H) return bail("EXR tile outside the data window");
-            bw = std::min<int>((int)p.tile_w, (int)W - x0);
-            bh = std::min<int>((int)p.tile_h, (int)H - y0);
+            // origins in 64 bits: tx * tile_w overflows an int for crafted tile coordinates
+            const int64_t x064 = (int64_t)tx * (int64_t)p.tile_w, y064 = (int64_t)ty * (int64_t)p.tile_h;
+            if (tx < 0 || ty < 0 || x064 >= (int64_t)W || y064 >= (int64_t)H) return bail("EXR tile outside the data window");
+            x0 = (int)x064;
+            y0 = (int)y064;
+            bw = (int)std::min<int64_t>((int64_t)p.tile_w, (int64_t)W - x064);
+            bh = (int)std::min<int64_t>((int64_t)p.tile_h, (int64_t)H - y064);
         } else {
             const int32_t y = c.i32();
             if (!c.ok) return bail("truncated EXR chunk header");
@@ -482,7 +489,7 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
             }
         }
     }
-    *out_rgb = img;
+    *out_rgb = img_owner.release();
     *out_w = W;
     *out_h = H;
     return IR_OK;
@@ -502,6 +509,20 @@ void put_attr(std::vector<uint8_t>& o, const char* name, const char* type, const
     o.insert(o.end(), v.begin(), v.end());
 }
 
+// Nothing thrown by the containers below (bad_alloc / length_error on a hostile header) may cross the C ABI.
+template <class F>
+int guarded(const char* who, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return set_err(IR_ENOMEM, std::string(who) + ": out of host memory");
+    } catch (const std::exception& e) {
+        return set_err(IR_EIO, std::string(who) + ": " + e.what());
+    } catch (...) {
+        return set_err(IR_EIO, std::string(who) + ": unexpected failure");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -512,14 +533,22 @@ int ir_exr_load(const char* path, float** out_rgb, uint32_t* out_w, uint32_t* ou
     if (!path || !out_rgb || !out_w || !out_h) return set_err(IR_EINVAL, "ir_exr_load: NULL argument");
     *out_rgb = nullptr;
     *out_w = *out_h = 0;
-    FILE* f = std::fopen(path, "rb");
-    if (!f) return set_err(IR_EIO, std::string("cannot open ") + path);
-    std::vector<uint8_t> bytes;
-    uint8_t buf[1 << 16];
-    size_t k;
-    while ((k = std::fread(buf, 1, sizeof(buf), f)) > 0) bytes.insert(bytes.end(), buf, buf + k);
-    std::fclose(f);
-    return load_from_memory(bytes.data(), bytes.size(), out_rgb, out_w, out_h);
+    return guarded("ir_exr_load", [&]() -> int {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) return set_err(IR_EIO, std::string("cannot open ") + path);
+        std::vector<uint8_t> bytes;
+        try {
+            uint8_t buf[1 << 16];
+            size_t k;
+            while ((k = std::fread(buf, 1, sizeof(buf), f)) > 0) bytes.insert(bytes.end(), buf, buf + k);
+        } catch (...) {
+            std::fclose(f);
+            throw;
+        }
+        std::fclose(f);
+        const int rc = load_from_memory(bytes.data(), bytes.size(), out_rgb, out_w, out_h);
+        return rc;
+    });
 }
 
 int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int compression, int pixel_type) {
@@ -527,6 +556,7 @@ int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int 
     if (compression < 0 || compression > 5)
         return set_err(IR_EINVAL, "ir_exr_save: compression must be 0 (NONE), 1 (RLE), 2 (ZIPS), 3 (ZIP), 4 (PIZ) or 5 (PXR24)");
     if (pixel_type != 1 && pixel_type != 2) return set_err(IR_EINVAL, "ir_exr_save: pixel_type must be 1 (HALF) or 2 (FLOAT)");
+    return guarded("ir_exr_save", [&]() -> int {
     std::vector<uint8_t> o;
     put_i32(o, 20000630);
     put_i32(o, 2);
@@ -627,6 +657,7 @@ int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int 
     const int rc = std::fclose(f);
     if (wr != o.size() || rc != 0) return set_err(IR_EIO, std::string("short write to ") + path);
     return IR_OK;
+    });
 }
 
 }  // extern "C"
@@ -653,6 +684,7 @@ void png_chunk(std::vector<uint8_t>& o, const char type[4], const uint8_t* data,
 int ir_png_save(const char* path, const uint32_t* argb, uint32_t w, uint32_t h) {
     if (!path || !argb || w == 0 || h == 0) return set_err(IR_EINVAL, "ir_png_save: NULL or empty image");
     if ((uint64_t)w * h > (1ull << 28)) return set_err(IR_ELIMIT, "ir_png_save: image too large");
+    return guarded("ir_png_save", [&]() -> int {
     std::vector<uint8_t> raw;
     raw.reserve((size_t)h * (1 + 3 * (size_t)w));
     for (uint32_t y = 0; y < h; ++y) {
@@ -679,4 +711,5 @@ int ir_png_save(const char* path, const uint32_t* argb, uint32_t w, uint32_t h) 
     const bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
     if (fclose(f) != 0 || !ok) return set_err(IR_EIO, std::string("ir_png_save: write failed: ") + path);
     return IR_OK;
+    });
 }

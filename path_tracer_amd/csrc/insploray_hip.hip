@@ -17,99 +17,15 @@
 #include <vector>
 
 #include "../../include/insploray_hip.h"
+#include "ir_internal.h"
 #include "lbvh.h"
 #include "pt_lbvh_build.h"
 #include "pt_kernels.h"
 #include "sky_distribution.h"
 
-namespace {
+namespace irx {
 
 thread_local std::string g_global_error;
-
-struct DeviceBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
-}  // namespace
-
-struct ir_context {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    mutable std::string err;
-
-    // scene (host copies kept so that the per-sphere shading table can be rebuilt when either side changes)
-    std::vector<float> h_spheres;   // n x 4
-    std::vector<int32_t> h_matid;   // n
-    std::vector<float> h_materials; // m x 9
-    bool shade_dirty = true;
-    bool fast_materials = false;
-    uint32_t n_spheres = 0;
-    DeviceBuf d_spheres, d_shade;
-    // LBVH (built before the first launch that needs it, on the host or on the device: ir_set_accel_build)
-    DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index, d_bvh_scratch;
-    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_stack = 0;
-    bool bvh_valid = false;
-    int bvh_build = IR_BUILD_AUTO;
-    int bvh_built_by = IR_BUILD_HOST;
-    uint32_t bvh_topology_n = 0;  // sphere count whose device-built radix tree is still in d_bvh_scratch (0 = none)
-    double bvh_build_seconds = 0.0;
-    float sky[3] = {0.0f, 0.0f, 0.0f};
-    DeviceBuf d_skybox;
-    uint32_t sky_w = 0, sky_h = 0;
-    int sky_filter = IR_SKY_NEAREST;
-    int sky_sampling = IR_SKY_SAMPLING_BSDF;
-    DeviceBuf d_sky_marginal, d_sky_cond, d_sky_pdf, d_sky_marginal_guide, d_sky_cond_guide;
-    bool sky_tables_valid = false;
-    int accel = IR_ACCEL_AUTO;
-
-    // camera
-    bool have_pinhole = false;
-    float cam_m[16] = {0};
-    float cam_pos[3] = {0};
-    float cam_fov = 0.0f, cam_aspect = 1.0f;
-    DeviceBuf d_rays;
-    uint32_t rays_w = 0, rays_h = 0;
-
-    // integrator (reference defaults, renderer.rs:38-41)
-    uint32_t bounces = 5, rr_start = 2;
-    uint32_t sample_block = 128;
-    DeviceBuf d_partials;
-    // wavefront schedule: path queues and per-sample values (allocated on first use)
-    int schedule = IR_SCHEDULE_AUTO;
-    bool wf_check_overflow = false;
-    uint32_t wf_max_paths = 128u << 20;
-    DeviceBuf d_wf_queue[2], d_wf_counts, d_wf_values, d_wf_prim, d_wf_tileacc;
-    uint64_t seed = 0x0123456789ABCDEFull;
-
-    // partition
-    int part_mode = IR_PARTITION_NONE;
-    uint32_t rank = 0, world = 1;
-
-    // film
-    uint32_t width = 0, height = 0;
-    DeviceBuf d_sum, d_counts, d_argb, d_hit_idx, d_hit_t;
-    uint32_t* h_argb = nullptr;  // pinned host frame handed out by ir_map_output_argb
-    size_t h_argb_bytes = 0;
-    void* ext_sum = nullptr;
-    void* ext_counts = nullptr;
-    uint32_t ext_w = 0, ext_h = 0;
-    uint32_t samples_done = 0;
-
-    // stats
-    bool stats_enabled = false;
-    DeviceBuf d_stats;
-    bool stats_valid = false;
-
-    // timing
-    double last_seconds = 0.0;
-    bool events_recorded = false;
-    uint32_t last_launches = 0;
-};
-
-namespace {
 
 int fail(const ir_context* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -124,18 +40,6 @@ int fail(const ir_context* ctx, int code, const char* fmt, ...) {
     }
     return code;
 }
-
-#define IR_HIP(ctx, call)                                                                              \
-    do {                                                                                               \
-        hipError_t e_ = (call);                                                                        \
-        if (e_ != hipSuccess) return fail(ctx, IR_EDEVICE, "%s: %s", #call, hipGetErrorString(e_));    \
-    } while (0)
-
-#define IR_TRY(expr)                 \
-    do {                             \
-        int rc_ = (expr);            \
-        if (rc_ != IR_OK) return rc_; \
-    } while (0)
 
 int ensure(ir_context* ctx, DeviceBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -166,7 +70,6 @@ int use_device(const ir_context* ctx) {
     return IR_OK;
 }
 
-// blocking upload through the context's stream
 int upload(ir_context* ctx, DeviceBuf& b, const void* src, size_t bytes) {
     IR_TRY(ensure(ctx, b, bytes));
     if (bytes) {
@@ -176,8 +79,11 @@ int upload(ir_context* ctx, DeviceBuf& b, const void* src, size_t bytes) {
     return IR_OK;
 }
 
-float4* film_sum(ir_context* ctx) { return (float4*)(ctx->ext_sum ? ctx->ext_sum : ctx->d_sum.p); }
-uint32_t* film_counts(ir_context* ctx) { return (uint32_t*)(ctx->ext_counts ? ctx->ext_counts : ctx->d_counts.p); }
+}  // namespace irx
+
+using namespace irx;
+
+namespace {
 
 // Scene -> device tables.  Material resolution follows integrator.rs:53-60 (material_id < 0 or out of range
 // => DEFAULT_MATERIAL, :8-14); brdf = albedo / PI (:68) and emission_color * emissive_power (:62) do not depend
@@ -222,6 +128,41 @@ int selected_accel(const ir_context* ctx) {
     if (ctx->accel == IR_ACCEL_LINEAR) return pt::kAccelLinear;
     return ctx->n_spheres >= kAutoLbvhFrom ? pt::kAccelLbvh : pt::kAccelLinear;
 }
+
+// Samples per accumulation block of a render when ir_set_sample_block selected IR_SAMPLE_BLOCK_AUTO: 128, halved (not
+// below 8) until the launch has at least kAutoMinWorkgroups workgroups, so that small frames and low sample counts still
+// fill the 256 CUs several times over (C1, 800x450x64: 1407 workgroups with one block of 64).  A pure function of the
+// workgroups per sample block and spp, so that a caller (and the oracle in the tests) can reproduce the sum order.
+constexpr uint32_t kAutoMinWorkgroups = 8192;
+uint32_t auto_sample_block(uint32_t wgs_per_block, uint32_t spp) {
+    uint32_t sb = 128;
+    while (sb > 8 && (uint64_t)wgs_per_block * ((spp + sb - 1) / sb) < kAutoMinWorkgroups) sb /= 2;
+    return sb;
+}
+
+// Scratch of ir_render_noalloc: the block sums of one launch (what ir_render keeps in a hipMalloc'ed buffer).  One copy
+// per GPU the library runs on, held until the process ends.  Host code never passes this NAME to a kernel or a memset:
+// ir_create asks each device for ITS copy's address (hipGetSymbolAddress) and keeps it in g_noalloc_scratch[device].
+constexpr size_t kNoAllocScratchBytes = 128ull << 20;
+__device__ __align__(256) float4 g_noalloc_scratch_array[kNoAllocScratchBytes / sizeof(float4)];
+constexpr int kMaxDevices = 64;
+void* g_noalloc_scratch[kMaxDevices] = {nullptr};
+
+int init_noalloc_scratch(int device, hipError_t* err) {  // with `device` current
+    if (device < 0 || device >= kMaxDevices) return IR_OK;  // such a device simply has no no-alloc entry point
+    if (g_noalloc_scratch[device]) return IR_OK;
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch_array));
+    if (e != hipSuccess || !p) {
+        *err = e;
+        return IR_EDEVICE;
+    }
+    g_noalloc_scratch[device] = p;
+    return IR_OK;
+}
+
+// block sums of one launch (ir_render): at most this much scratch, see render_impl
+constexpr size_t kPartialsBudgetBytes = 6ull << 30;
 
 // AUTO builds on the device from this many spheres (measured crossover with the host build, tools/lbvh_build_times.py)
 constexpr uint32_t kAutoDeviceBuildFrom = 2048;
@@ -382,6 +323,7 @@ int ir_create(ir_context** out_ctx, int device) {
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if (init_noalloc_scratch(device, &e) != IR_OK) return bail("hipGetSymbolAddress(static scratch)", e);
     if ((e = pt::init_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
     if ((e = pt::init_wavefront_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
     *out_ctx = ctx;
@@ -392,6 +334,7 @@ void ir_destroy(ir_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
     release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_rays);
     if (ctx->h_argb) (void)hipHostFree(ctx->h_argb);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
@@ -430,15 +373,26 @@ int ir_set_spheres(ir_context* ctx, const float* spheres_xyzr, const int32_t* ma
     // geometry only.
     const bool same_ids = n == ctx->n_spheres && (n == 0 || memcmp(ctx->h_matid.data(), material_id, (size_t)n * 4) == 0);
     const bool same_geometry = n == ctx->n_spheres && (n == 0 || memcmp(ctx->h_spheres.data(), spheres_xyzr, (size_t)n * 16) == 0);
+    if (!same_geometry) {
+        // The device copy goes first: a failed upload (ensure() may already have freed the old buffer) must not leave
+        // host mirrors that make a retry with the same scene look unchanged.
+        ctx->bvh_valid = false;
+        const int rc = upload(ctx, ctx->d_spheres, spheres_xyzr, (size_t)n * 4 * sizeof(float));
+        if (rc != IR_OK) {
+            ctx->bvh_topology_n = 0;
+            ctx->h_spheres.clear();
+            ctx->h_matid.clear();
+            ctx->n_spheres = 0;
+            ctx->shade_dirty = true;
+            return rc;
+        }
+        ctx->h_spheres.assign(spheres_xyzr, spheres_xyzr + (size_t)n * 4);
+    }
     ctx->n_spheres = n;
     if (!same_ids) {
         ctx->h_matid.assign(material_id, material_id + n);
         ctx->shade_dirty = true;
     }
-    if (same_geometry) return IR_OK;
-    ctx->bvh_valid = false;
-    ctx->h_spheres.assign(spheres_xyzr, spheres_xyzr + (size_t)n * 4);
-    IR_TRY(upload(ctx, ctx->d_spheres, ctx->h_spheres.data(), (size_t)n * 4 * sizeof(float)));
     return IR_OK;
 }
 
@@ -565,9 +519,19 @@ int ir_set_schedule(ir_context* ctx, int schedule, uint32_t max_paths) {
 
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block) {
     if (!ctx) return IR_EINVAL;
-    if (samples_per_block == 0 || samples_per_block > 4096)
-        return fail(ctx, IR_EINVAL, "ir_set_sample_block: %u not in [1, 4096]", samples_per_block);
+    if (samples_per_block > 4096)
+        return fail(ctx, IR_EINVAL, "ir_set_sample_block: %u not in [1, 4096] and not IR_SAMPLE_BLOCK_AUTO (0)", samples_per_block);
     ctx->sample_block = samples_per_block;
+    return IR_OK;
+}
+
+int ir_get_sample_block(const ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t* out_samples_per_block) {
+    if (!ctx) return IR_EINVAL;
+    if (!out_samples_per_block) return fail(ctx, IR_EINVAL, "ir_get_sample_block: NULL");
+    const uint32_t tiles = ((width + pt::kTile - 1) / pt::kTile) * ((height + pt::kTile - 1) / pt::kTile);
+    const bool by_tiles = ctx->part_mode == IR_PARTITION_TILES;
+    const uint32_t wgs = pt::owned_tiles(tiles, by_tiles ? ctx->rank : 0, by_tiles ? ctx->world : 1) * pt::kBlocksPerTile;
+    *out_samples_per_block = ctx->sample_block ? ctx->sample_block : auto_sample_block(wgs, spp);
     return IR_OK;
 }
 
@@ -582,37 +546,73 @@ int ir_set_partition(ir_context* ctx, int mode, uint32_t rank, uint32_t world) {
     return IR_OK;
 }
 
-int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate) {
-    if (!ctx) return IR_EINVAL;
+}  // extern "C"
+
+namespace {
+
+// Device tables every launch needs.  May allocate and upload; after it succeeds, and until the scene, the sky or a
+// structure setting changes, scene_is_prepared() holds and a render allocates nothing for the scene.
+int prepare_scene(ir_context* ctx) {
+    IR_TRY(rebuild_shade(ctx));
+    IR_TRY(ensure(ctx, ctx->d_spheres, 16));
+    IR_TRY(ensure_bvh(ctx));
+    const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
+    if (skymis && ctx->schedule != IR_SCHEDULE_WAVEFRONT) IR_TRY(ensure_sky_tables(ctx));
+    return IR_OK;
+}
+bool scene_is_prepared(const ir_context* ctx) {
+    if (ctx->shade_dirty || !ctx->d_shade.p || !ctx->d_spheres.p) return false;
+    if (selected_accel(ctx) == pt::kAccelLbvh && !ctx->bvh_valid) return false;
+    const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
+    return !skymis || ctx->sky_tables_valid;
+}
+
+// The body of ir_render_async and ir_render_noalloc.  ext_* == nullptr: the context's film (resized, allocated);
+// otherwise the caller's buffers and the static scratch, and nothing below may allocate.
+int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate, float4* ext_sum,
+                uint32_t* ext_counts) {
+    const bool noalloc = ext_sum != nullptr;
+    const char* who = noalloc ? "ir_render_noalloc" : "ir_render";
     if ((uint64_t)width * height > 0x7fffffffull / 8)
-        return fail(ctx, IR_ELIMIT, "ir_render: %ux%u exceeds the supported frame size", width, height);
+        return fail(ctx, IR_ELIMIT, "%s: %ux%u exceeds the supported frame size", who, width, height);
     IR_TRY(use_device(ctx));
     ctx->events_recorded = false;
     ctx->last_launches = 0;
     ctx->stats_valid = false;
-    IR_TRY(set_size(ctx, width, height));
+    ctx->output_combined = false;
+    if (!noalloc) IR_TRY(set_size(ctx, width, height));
     if (width == 0 || height == 0) return IR_OK;  // RayTracer::new(0,0) then render(…,0,0,…) is a no-op loop
     const size_t n = (size_t)width * height;
+    float4* const sum = noalloc ? ext_sum : film_sum(ctx);
+    uint32_t* const counts = noalloc ? ext_counts : film_counts(ctx);
+    if (noalloc) {
+        // before anything is enqueued: a frame whose block sums do not fit the static scratch is refused outright
+        if (n > kNoAllocScratchBytes / (2 * sizeof(float4)))
+            return fail(ctx, IR_ELIMIT, "%s: %ux%u pixels exceed the %zu the %zu MiB static scratch holds two block sums for", who,
+                        width, height, kNoAllocScratchBytes / (2 * sizeof(float4)), kNoAllocScratchBytes >> 20);
+        if (ctx->schedule == IR_SCHEDULE_WAVEFRONT)
+            return fail(ctx, IR_ESTATE, "%s: the wavefront schedule allocates its path queues; select IR_SCHEDULE_AUTO/REGENERATION", who);
+        if (ctx->stats_enabled) return fail(ctx, IR_ESTATE, "%s: statistics need an allocated counter buffer; use ir_render", who);
+        if (!scene_is_prepared(ctx))
+            return fail(ctx, IR_ESTATE, "%s: the scene's device tables are stale; call ir_render (spp 0 is enough) once after "
+                                        "changing the scene, the sky or the closest-hit structure", who);
+    } else {
+        IR_TRY(prepare_scene(ctx));
+    }
     if (!accumulate) {
         // renderer.rs:99-103
-        IR_HIP(ctx, hipMemsetAsync(film_sum(ctx), 0, n * sizeof(float4), ctx->stream));
-        IR_HIP(ctx, hipMemsetAsync(film_counts(ctx), 0, n * sizeof(uint32_t), ctx->stream));
+        IR_HIP(ctx, hipMemsetAsync(sum, 0, n * sizeof(float4), ctx->stream));
+        IR_HIP(ctx, hipMemsetAsync(counts, 0, n * sizeof(uint32_t), ctx->stream));
         ctx->samples_done = 0;
     }
     if (spp == 0) return IR_OK;
     const float* rays = nullptr;
     IR_TRY(check_camera(ctx, width, height, &rays));
-    IR_TRY(rebuild_shade(ctx));
-    IR_TRY(ensure(ctx, ctx->d_spheres, 16));
-    IR_TRY(ensure_bvh(ctx));
     const int accel = selected_accel(ctx);
     // sky importance sampling needs a sky image; with a constant sky colour there is nothing to importance-sample
     const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
-    if (skymis) {
-        if (ctx->schedule == IR_SCHEDULE_WAVEFRONT)
-            return fail(ctx, IR_ESTATE, "ir_render: IR_SKY_SAMPLING_MIS is implemented for the regeneration schedule only");
-        IR_TRY(ensure_sky_tables(ctx));
-    }
+    if (skymis && ctx->schedule == IR_SCHEDULE_WAVEFRONT)
+        return fail(ctx, IR_ESTATE, "ir_render: IR_SKY_SAMPLING_MIS is implemented for the regeneration schedule only");
 
     pt::RenderArgs a;
     memset(&a, 0, sizeof(a));
@@ -640,8 +640,8 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     a.rr_start = ctx->rr_start;
     a.seed_lo = (uint32_t)(ctx->seed & 0xffffffffu);
     a.seed_hi = (uint32_t)(ctx->seed >> 32);
-    a.sum = film_sum(ctx);
-    a.counts = film_counts(ctx);
+    a.sum = sum;
+    a.counts = counts;
     a.tiles_x = (width + pt::kTile - 1) / pt::kTile;
     a.n_tiles = a.tiles_x * ((height + pt::kTile - 1) / pt::kTile);
     a.tile_rank = (ctx->part_mode == IR_PARTITION_TILES) ? ctx->rank : 0;
@@ -716,12 +716,25 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     const double unit = (double)n * (double)(accel == pt::kAccelLbvh ? 64 : (ctx->n_spheres < 8 ? 8 : ctx->n_spheres));
     uint32_t chunk = (uint32_t)std::fmin(4096.0, std::fmax(1.0, 4.0e12 / unit));
     // whole sample blocks per launch, so that the block structure does not depend on the chunking
-    const uint32_t sb = ctx->sample_block;
+    const uint32_t owned_wgs = pt::owned_tiles(a.n_tiles, a.tile_rank, a.tile_world) * pt::kBlocksPerTile;
+    const uint32_t sb = ctx->sample_block ? ctx->sample_block : auto_sample_block(owned_wgs, spp);
+    ctx->last_sample_block = sb;
     chunk = chunk < sb ? sb : chunk / sb * sb;
+    // ... and bound the block sums of one launch (16 B per pixel and block): more launches rather than more memory.  A
+    // small sample_block is what a caller sets to get the reference's per-sample sum order; it must not cost 100 GB.
+    const size_t partials_budget = noalloc ? kNoAllocScratchBytes : kPartialsBudgetBytes;
+    size_t budget_blocks = partials_budget / (n * sizeof(float4));
+    if (budget_blocks < 2) budget_blocks = 2;  // (ir_render_noalloc refused such a frame above)
+    if ((size_t)chunk / sb > budget_blocks) chunk = (uint32_t)budget_blocks * sb;
     const uint32_t max_blocks = ((spp < chunk ? spp : chunk) + sb - 1) / sb;
-    if (max_blocks > 1) IR_TRY(ensure(ctx, ctx->d_partials, (size_t)max_blocks * n * sizeof(float4)));
     a.sample_block = sb;
-    a.partials = (float4*)ctx->d_partials.p;
+    if (noalloc) {
+        a.partials = (ctx->device < kMaxDevices) ? (float4*)g_noalloc_scratch[ctx->device] : nullptr;
+        if (!a.partials) return fail(ctx, IR_ESTATE, "%s: no static scratch on device %d", who, ctx->device);
+    } else {
+        if (max_blocks > 1) IR_TRY(ensure(ctx, ctx->d_partials, (size_t)max_blocks * n * sizeof(float4)));
+        a.partials = (float4*)ctx->d_partials.p;
+    }
     IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     uint32_t done = 0;
     while (done < spp) {
@@ -740,6 +753,15 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
         ctx->stats_enabled = false;  // one render only
     }
     return IR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate) {
+    if (!ctx) return IR_EINVAL;
+    return render_impl(ctx, width, height, spp, accumulate, nullptr, nullptr);
 }
 
 int ir_synchronize(ir_context* ctx) {
@@ -772,7 +794,10 @@ int ir_get_output_argb(ir_context* ctx, uint32_t* out, size_t n) {
     if (!out) return fail(ctx, IR_EINVAL, "ir_get_output_argb: NULL");
     IR_TRY(use_device(ctx));
     IR_TRY(ensure(ctx, ctx->d_argb, n * sizeof(uint32_t)));
-    IR_HIP(ctx, pt::launch_resolve(film_sum(ctx), film_counts(ctx), (uint32_t*)ctx->d_argb.p, n, ctx->stream));
+    const float4* sum;
+    const uint32_t* counts;
+    IR_TRY(output_film(ctx, &sum, &counts));
+    IR_HIP(ctx, pt::launch_resolve(sum, counts, (uint32_t*)ctx->d_argb.p, n, ctx->stream));
     IR_HIP(ctx, hipMemcpyAsync(out, ctx->d_argb.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IR_OK;
@@ -798,7 +823,10 @@ int ir_map_output_argb(ir_context* ctx, const uint32_t** out, size_t* out_n) {
         ctx->h_argb_bytes = n * sizeof(uint32_t);
     }
     IR_TRY(ensure(ctx, ctx->d_argb, n * sizeof(uint32_t)));
-    IR_HIP(ctx, pt::launch_resolve(film_sum(ctx), film_counts(ctx), (uint32_t*)ctx->d_argb.p, n, ctx->stream));
+    const float4* sum;
+    const uint32_t* counts;
+    IR_TRY(output_film(ctx, &sum, &counts));
+    IR_HIP(ctx, pt::launch_resolve(sum, counts, (uint32_t*)ctx->d_argb.p, n, ctx->stream));
     IR_HIP(ctx, hipMemcpyAsync(ctx->h_argb, ctx->d_argb.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = ctx->h_argb;
@@ -811,8 +839,11 @@ int ir_get_radiance(ir_context* ctx, float* sum_rgba, uint32_t* counts, size_t n
     if (n != have) return fail(ctx, IR_EINVAL, "ir_get_radiance: n=%zu but the frame has %zu pixels", n, have);
     if (n == 0) return IR_OK;
     IR_TRY(use_device(ctx));
-    if (sum_rgba) IR_HIP(ctx, hipMemcpyAsync(sum_rgba, film_sum(ctx), n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    if (counts) IR_HIP(ctx, hipMemcpyAsync(counts, film_counts(ctx), n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    const float4* d_sum;
+    const uint32_t* d_counts;
+    IR_TRY(output_film(ctx, &d_sum, &d_counts));
+    if (sum_rgba) IR_HIP(ctx, hipMemcpyAsync(sum_rgba, d_sum, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (counts) IR_HIP(ctx, hipMemcpyAsync(counts, d_counts, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IR_OK;
 }
@@ -823,6 +854,7 @@ int ir_set_radiance(ir_context* ctx, const float* sum_rgba, const uint32_t* coun
     if (n != have) return fail(ctx, IR_EINVAL, "ir_set_radiance: n=%zu but the frame has %zu pixels", n, have);
     if (n == 0) return IR_OK;
     IR_TRY(use_device(ctx));
+    ctx->output_combined = false;
     if (sum_rgba) IR_HIP(ctx, hipMemcpyAsync(film_sum(ctx), sum_rgba, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     if (counts) IR_HIP(ctx, hipMemcpyAsync(film_counts(ctx), counts, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -899,6 +931,7 @@ int ir_bind_accumulator(ir_context* ctx, void* d_sum_rgba, void* d_counts, uint3
     if (!ctx) return IR_EINVAL;
     IR_TRY(use_device(ctx));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->output_combined = false;
     if (!d_sum_rgba && !d_counts) {
         ctx->ext_sum = ctx->ext_counts = nullptr;
         ctx->ext_w = ctx->ext_h = 0;

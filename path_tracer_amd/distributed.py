@@ -1,5 +1,12 @@
-"""Multi-GPU host logic: one process per GPU, partial radiance buffers combined with one reduce over RCCL
-(torch.distributed backend "nccl"; "gloo" on CPU tensors in the tests).
+"""Multi-GPU host logic: one process per GPU, partial radiance buffers combined on a root rank.
+
+Two routes to the same exchange step:
+  * NativeExchange — the library's own RCCL step (ir_comm_init / ir_combine, csrc/insploray_comm.hip): a grouped reduce for
+    the sample-range partition, a gather of owned tiles for the tile partition, on a stream of its own so that the next
+    render overlaps it.  torch.distributed (any backend) only carries the 128-byte rendezvous id.  This is what a Rust
+    host would call, and what bench.py uses;
+  * combine_partials / DistributedFilm — reduce of torch tensors bound as the accumulator (backend "nccl" = RCCL on the
+    GPU, "gloo" on CPU tensors in the tests): for hosts that already live in torch.
 
 The reference has no distributed code (its only parallelism is the 4-thread tile pool, renderer.rs:105-159); the
 path shards naturally because every pixel-sample is independent and the accumulator is additive
@@ -71,3 +78,43 @@ class DistributedFilm:
 
     def combine(self, dst=0, all_ranks=False):
         return combine_partials(self.sums, self.counts, dst=dst, all_ranks=all_ranks)
+
+
+class NativeExchange:
+    """ir_comm_init + ir_combine for a RayTracer.  `broadcast_id(bytes_or_None) -> bytes` hands rank 0's rendezvous id to
+    every rank; the default uses torch.distributed.broadcast_object_list on the default group."""
+
+    def __init__(self, tracer, rank, world, broadcast_id=None):
+        import ctypes as C
+        self.tracer, self.rank, self.world = tracer, int(rank), int(world)
+        buf = C.create_string_buffer(_capi.IR_COMM_ID_BYTES)
+        if self.rank == 0:
+            _capi.check(None, _capi.lib.ir_comm_unique_id(buf))
+        ident = buf.raw if self.rank == 0 else None
+        if self.world > 1:
+            if broadcast_id is None:
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                ident = box[0]
+            else:
+                ident = broadcast_id(ident)
+        if not isinstance(ident, (bytes, bytearray)) or len(ident) != _capi.IR_COMM_ID_BYTES:
+            raise ValueError("rendezvous id must be %d bytes" % _capi.IR_COMM_ID_BYTES)
+        _capi.check(tracer._ctx, _capi.lib.ir_comm_init(tracer._ctx, bytes(ident), self.rank, self.world))
+
+    def combine(self, root=0):
+        """Blocking: when it returns on the root, get_radiance / get_output show the combined film."""
+        _capi.check(self.tracer._ctx, _capi.lib.ir_combine(self.tracer._ctx, int(root)))
+
+    def combine_async(self, root=0):
+        _capi.check(self.tracer._ctx, _capi.lib.ir_combine_async(self.tracer._ctx, int(root)))
+
+    def wait(self):
+        _capi.check(self.tracer._ctx, _capi.lib.ir_combine_wait(self.tracer._ctx))
+
+    def last_ms(self):
+        return float(_capi.lib.ir_last_combine_ms(self.tracer._ctx))
+
+    def close(self):
+        if getattr(self.tracer, "_ctx", None):
+            _capi.lib.ir_comm_destroy(self.tracer._ctx)

@@ -54,9 +54,10 @@ class RayTracer:
         """renderer.rs:75-77: reset the accumulator, then one sample per pixel."""
         self.render(scene, width, height, False)
 
-    def render(self, scene, width, height, acc, spp=1):
+    def render(self, scene, width, height, acc, spp=1, blocking=True):
         """renderer.rs:95-162.  Blocks until the frame is rendered.  `spp` (extension) adds that many samples per
-        pixel in one call; spp=1 is the reference behaviour."""
+        pixel in one call; spp=1 is the reference behaviour.  blocking=False (extension) returns once the launches are
+        enqueued on the context's stream (ir_render_async); synchronize() waits."""
         ctx = self._ctx
         width, height = int(width), int(height)
         # set_size, renderer.rs:80-93: the camera learns the resolution on every render
@@ -65,8 +66,14 @@ class RayTracer:
         self._upload_camera(width, height)
         _capi.check(ctx, _capi.lib.ir_set_integrator(ctx, int(self.bounces), int(self.max_compulsory_bounces),
                                                      C.c_uint64(self.seed)))
+        if not blocking:
+            _capi.check(ctx, _capi.lib.ir_render_async(ctx, width, height, int(spp), 1 if acc else 0))
+            return
         _capi.check(ctx, _capi.lib.ir_render(ctx, width, height, int(spp), 1 if acc else 0))
         self._last_render_time = _capi.lib.ir_last_render_seconds(ctx)
+
+    def synchronize(self):
+        _capi.check(self._ctx, _capi.lib.ir_synchronize(self._ctx))
 
     def get_output(self):
         """renderer.rs:164-169: resolved 0xAARRGGBB pixels, row 0 = bottom row (the frontend flips)."""
@@ -95,8 +102,15 @@ class RayTracer:
         _capi.check(self._ctx, _capi.lib.ir_set_schedule(self._ctx, int(schedule), int(max_paths)))
 
     def set_sample_block(self, samples_per_block):
-        """Samples per accumulation block of a multi-sample render call (ir_set_sample_block; default 128)."""
+        """Samples per accumulation block of a multi-sample render call (ir_set_sample_block; default 128,
+        IR_SAMPLE_BLOCK_AUTO = 0 sizes the blocks from the launch grid)."""
         _capi.check(self._ctx, _capi.lib.ir_set_sample_block(self._ctx, int(samples_per_block)))
+
+    def get_sample_block(self, width, height, spp):
+        """Samples per block a render of this shape would use (ir_get_sample_block)."""
+        out = C.c_uint32()
+        _capi.check(self._ctx, _capi.lib.ir_get_sample_block(self._ctx, int(width), int(height), int(spp), C.byref(out)))
+        return out.value
 
     def set_partition(self, mode, rank, world):
         _capi.check(self._ctx, _capi.lib.ir_set_partition(self._ctx, int(mode), int(rank), int(world)))

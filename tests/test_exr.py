@@ -212,6 +212,145 @@ def test_example_scene_falls_back_without_asset(tmp_path, monkeypatch, capsys):
     assert sc.skybox is not None and (sc.skybox.width, sc.skybox.height) == (8, 4)
 
 
+def _zip_block(raw):
+    """OpenEXR ZIP/ZIPS block: de-interleave even/odd bytes, delta-code, deflate; stored raw if that is not smaller."""
+    b = np.frombuffer(raw, dtype=np.uint8)
+    re = np.concatenate([b[0::2], b[1::2]]).astype(np.int32)
+    d = re.copy()
+    d[1:] = (re[1:] - re[:-1] + 128 + 256) & 0xFF
+    z = zlib.compress(d.astype(np.uint8).tobytes())
+    return z if len(z) < len(raw) else raw
+
+
+def _part_header(chs, w, h, comp, tiles=None, name=None, chunk_count=None):
+    hdr = _attr("channels", "chlist", _chlist(chs))
+    hdr += _attr("compression", "compression", bytes([comp]))
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr += _attr("dataWindow", "box2i", box) + _attr("displayWindow", "box2i", box)
+    hdr += _attr("lineOrder", "lineOrder", bytes([0]))
+    hdr += _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
+    hdr += _attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    if tiles is not None:
+        hdr += _attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], 0))
+    if name is not None:  # multi-part attributes
+        hdr += _attr("name", "string", name.encode())
+        hdr += _attr("type", "string", b"tiledimage" if tiles is not None else b"scanlineimage")
+        hdr += _attr("chunkCount", "int", struct.pack("<i", chunk_count))
+    return hdr + b"\0"
+
+
+def _tile_chunks(chs, w, h, planes, comp, tw, th):
+    """[(tile header bytes, data)] in the offset table's order (ty major), level 0 only."""
+    out = []
+    for ty in range((h + th - 1) // th):
+        for tx in range((w + tw - 1) // tw):
+            x0, y0 = tx * tw, ty * th
+            bw, bh = min(tw, w - x0), min(th, h - y0)
+            raw = b""
+            for ly in range(bh):
+                for name, t in chs:
+                    v = planes[name][y0 + ly, x0:x0 + bw]
+                    raw += v.astype({0: np.uint32, 1: np.float16, 2: np.float32}[t]).tobytes()
+            out.append((struct.pack("<iiii", tx, ty, 0, 0), _zip_block(raw) if comp in (2, 3) else raw))
+    return out
+
+
+def _line_chunks(chs, w, h, planes, comp):
+    lpb = {0: 1, 2: 1, 3: 16}[comp]
+    out = []
+    for y0 in range(0, h, lpb):
+        raw = b""
+        for y in range(y0, min(h, y0 + lpb)):
+            for name, t in chs:
+                raw += planes[name][y].astype({0: np.uint32, 1: np.float16, 2: np.float32}[t]).tobytes()
+        out.append((struct.pack("<i", y0), _zip_block(raw) if comp in (2, 3) else raw))
+    return out
+
+
+def _assemble(version, headers, parts_chunks, multipart):
+    """File = magic, version, headers, offset tables (part order), chunks."""
+    head = struct.pack("<ii", 20000630, version) + b"".join(headers) + (b"\0" if multipart else b"")
+    n_entries = sum(len(c) for c in parts_chunks)
+    pos = len(head) + 8 * n_entries
+    tables, body = b"", b""
+    for pi, chunks in enumerate(parts_chunks):
+        for hdr, data in chunks:
+            tables += struct.pack("<Q", pos + len(body))
+            body += (struct.pack("<i", pi) if multipart else b"") + hdr + struct.pack("<i", len(data)) + data
+    return head + tables + body
+
+
+@pytest.mark.parametrize("comp", [0, 3])
+@pytest.mark.parametrize("tile", [(4, 4), (5, 3), (32, 32)])
+def test_handmade_tiled_file(tmp_path, comp, tile):
+    """Single-part tiled files (version bit 0x200) written here in Python: ragged edge tiles, HALF and UINT channels."""
+    w, h = 13, 9
+    rng = np.random.default_rng(7)
+    planes = {"A": rng.random((h, w)), "B": rng.random((h, w)), "G": rng.integers(0, 500, (h, w)).astype(np.float64),
+              "R": rng.random((h, w))}
+    chs = [("A", 1), ("B", 1), ("G", 0), ("R", 2)]
+    data = _assemble(2 | 0x200, [_part_header(chs, w, h, comp, tiles=tile)], [_tile_chunks(chs, w, h, planes, comp, *tile)], False)
+    p = tmp_path / "tiled.exr"
+    p.write_bytes(data)
+    img = pta.ExrImage.load_exr_image(p)
+    assert (img.width, img.height) == (w, h)
+    got = img.pixels_buffer.reshape(h, w, 3)
+    assert np.array_equal(got[..., 0], planes["R"].astype(np.float32))
+    assert np.array_equal(got[..., 1], planes["G"].astype(np.uint32).astype(np.float32))
+    assert np.array_equal(got[..., 2], planes["B"].astype(np.float16).astype(np.float32))
+
+
+@pytest.mark.parametrize("rgb_part_tiled", [False, True])
+def test_handmade_multipart_file(tmp_path, rgb_part_tiled):
+    """Multi-part file (version bit 0x1000): part 0 holds depth only, part 1 is the first part with R, G and B
+    (exr.rs:27 read_first_rgba_layer_from_file), part 2 another RGB layer that must not be picked."""
+    w, h = 11, 21
+    rng = np.random.default_rng(8)
+    z = {"Z": rng.random((h, w))}
+    rgb = {k: rng.random((h, w)) for k in "BGR"}
+    other = {k: rng.random((h, w)) for k in "BGR"}
+    c3 = [(k, 2) for k in "BGR"]
+    tile = (4, 8)
+    chunks = [_line_chunks([("Z", 2)], w, h, z, 3),
+              _tile_chunks(c3, w, h, rgb, 3, *tile) if rgb_part_tiled else _line_chunks(c3, w, h, rgb, 2),
+              _line_chunks(c3, w, h, other, 0)]
+    headers = [_part_header([("Z", 2)], w, h, 3, name="depth", chunk_count=len(chunks[0])),
+               _part_header(c3, w, h, 3 if rgb_part_tiled else 2, tiles=tile if rgb_part_tiled else None, name="beauty",
+                            chunk_count=len(chunks[1])),
+               _part_header(c3, w, h, 0, name="other", chunk_count=len(chunks[2]))]
+    p = tmp_path / "multi.exr"
+    p.write_bytes(_assemble(2 | 0x1000, headers, chunks, True))
+    got = pta.ExrImage.load_exr_image(p).pixels_buffer.reshape(h, w, 3)
+    for k, name in enumerate("RGB"):
+        assert np.array_equal(got[..., k], rgb[name].astype(np.float32))
+
+
+def test_crafted_tile_coordinates_and_counts_are_rejected(tmp_path):
+    """Hostile headers: tile origins that overflow 32 bits, tile sizes with the sign bit set, a chunkCount the file cannot
+    hold.  Each must come back as an error (the first one used to write 786 KB in front of the image)."""
+    w, h = 8, 2
+    planes = {k: np.ones((h, w)) for k in "BGR"}
+    c3 = [(k, 2) for k in "BGR"]
+    p = tmp_path / "evil.exr"
+    # tile_w = 65536, tile_h = 1; one chunk claims tx = 65535: x0 = 65535 * 65536 wraps to -65536 in 32 bits
+    tw, th = 65536, 1
+    chunks = _tile_chunks(c3, w, h, planes, 0, tw, th)
+    evil = [(struct.pack("<iiii", 65535, 0, 0, 0), np.ones(65536 * 3, dtype=np.float32).tobytes())] + chunks[1:]
+    p.write_bytes(_assemble(2 | 0x200, [_part_header(c3, w, h, 0, tiles=(tw, th))], [evil], False))
+    with pytest.raises(pta.InsplorayError, match="outside the data window"):
+        pta.ExrImage.load_exr_image(p)
+    for tw, th in [(0x80000000, 1), (1, 0xFFFFFFF0), (65537, 4)]:
+        p.write_bytes(_assemble(2 | 0x200, [_part_header(c3, w, h, 0, tiles=(tw, th))], [chunks], False))
+        with pytest.raises(pta.InsplorayError, match="tile size"):
+            pta.ExrImage.load_exr_image(p)
+    lines = _line_chunks(c3, w, h, planes, 0)
+    for count in (0x7FFFFFFF, 1 << 20):
+        p.write_bytes(_assemble(2 | 0x1000, [_part_header(c3, w, h, 0, name="a", chunk_count=count)], [lines], True))
+        with pytest.raises(pta.InsplorayError, match="offset table"):
+            pta.ExrImage.load_exr_image(p)
+
+
 @pytest.mark.parametrize("comp", [3, 4, 5])
 def test_corrupted_files_never_crash(tmp_path, comp):
     """Bit flips and truncations of valid files: the loader returns an error or an image, it never faults."""
@@ -260,3 +399,56 @@ def test_png_save_round_trip(tmp_path):
         save_png(tmp_path / "no_such_dir" / "x.png", np.zeros(4, dtype=np.uint32), 2, 2)
     with pytest.raises(ValueError):
         save_png(tmp_path / "x.png", np.zeros(5, dtype=np.uint32), 2, 2)
+
+
+def test_reader_under_address_sanitizer(tmp_path):
+    """The reader compiled for the host with -fsanitize=address,undefined (tests/cpp/exr_asan_main.cpp) over tiled,
+    multi-part, crafted and randomly corrupted files: no sanitizer report, every file answered with a code."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "path_tracer_amd", "csrc")
+    exe = tmp_path / "exr_asan"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-static-libasan", "-static-libubsan",
+                           os.path.join(root, "tests", "cpp", "exr_asan_main.cpp"), os.path.join(csrc, "exr_io.cpp"),
+                           os.path.join(csrc, "exr_codecs.cpp"), "-lz", "-o", str(exe)])
+    w, h = 13, 9
+    rng = np.random.default_rng(11)
+    planes = {k: rng.random((h, w)) for k in "BGR"}
+    c3 = [(k, 1) for k in "BGR"]
+    files = []
+
+    def add(name, data):
+        q = tmp_path / name
+        q.write_bytes(bytes(data))
+        files.append(str(q))
+
+    tiled = _assemble(2 | 0x200, [_part_header(c3, w, h, 3, tiles=(5, 4))], [_tile_chunks(c3, w, h, planes, 3, 5, 4)], False)
+    add("tiled.exr", tiled)
+    lines = _line_chunks(c3, w, h, planes, 3)
+    multi = _assemble(2 | 0x1000, [_part_header(c3, w, h, 3, name="a", chunk_count=len(lines)),
+                                   _part_header(c3, w, h, 3, tiles=(5, 4), name="b", chunk_count=6)],
+                      [lines, _tile_chunks(c3, w, h, planes, 3, 5, 4)], True)
+    add("multi.exr", multi)
+    evil_chunks = [(struct.pack("<iiii", 65535, 0, 0, 0), np.ones(65536 * 3, dtype=np.float16).tobytes())]
+    add("evil.exr", _assemble(2 | 0x200, [_part_header(c3, 8, 2, 0, tiles=(65536, 1))], [evil_chunks], False))
+    add("count.exr", _assemble(2 | 0x1000, [_part_header(c3, w, h, 3, name="a", chunk_count=0x7FFFFFFF)], [lines], True))
+    for base, tag in ((tiled, "t"), (multi, "m")):
+        for trial in range(150):
+            bad = bytearray(base)
+            if trial % 4 == 0:
+                bad = bad[: int(rng.integers(1, len(bad)))]
+            else:
+                for _ in range(int(rng.integers(1, 5))):
+                    i = int(rng.integers(8, len(bad)))  # headers included: tile sizes, windows, counts
+                    bad[i] ^= 1 << int(rng.integers(0, 8))
+            add(f"{tag}{trial}.exr", bad)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
+    r = subprocess.run([str(exe)] + files, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == len(files)
+    assert out[0].startswith("0 13x9") and out[1].startswith("0 13x9") and out[2].startswith("-") and out[3].startswith("-")

@@ -56,3 +56,17 @@ def test_two_ranks_rehearsal(workload, partition):
     w, h = (1920, 1080) if workload == "c2" else (3840, 2160)
     work = (2 if partition == "samples" else 1) * w * h * 8
     assert abs(d["value"] - work / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+
+
+def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses for N = 1): the parent spawns the
+    ranks itself, relays the one JSON line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--spp", "8", "--rehearse-one-gpu"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json_line(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "gloo" in d["exchange"]["how"]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--spp", "1", "--workload", "nonsense"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert bad.returncode != 0
