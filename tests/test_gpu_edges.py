@@ -136,7 +136,7 @@ def test_limits_are_errors_not_crashes(pta, tracer):
         tracer.render(scene, 70000, 70000, False)            # 4.9 G pixels: refused before anything is allocated
     assert e.value.code == _capi.IR_ELIMIT
     with pytest.raises(pta.InsplorayError):
-        tracer.set_sample_block(0)
+        tracer.set_sample_block(4097)  # (0 is IR_SAMPLE_BLOCK_AUTO)
     with pytest.raises(pta.InsplorayError):
         tracer.set_schedule(7)
     with pytest.raises(pta.InsplorayError):
