@@ -233,6 +233,21 @@ int ir_render(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, in
 /* Same, but returns after enqueueing on the context's stream (for callers that own the stream). */
 int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate);
 int ir_synchronize(ir_context* ctx);
+/* ir_render_async into the CALLER's device buffers, allocating nothing.  No counterpart in the reference: it is for
+ * callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * d_sum_rgba = width*height float4, d_counts = width*height u32, on the context's device; accumulate == 0 zeroes them
+ * first and restarts the sample sequence at 0, otherwise the samples continue the context's sequence
+ * (ir_samples_accumulated) as ir_render's would.  The context's own accumulator and size are not touched.  The block
+ * sums of a launch (ir_set_sample_block) go to a static 128 MiB device array instead of an allocated buffer, which
+ *   - limits the frame to 4 194 304 pixels (two block sums must fit; larger frames: IR_ELIMIT), launches are cut so
+ *     that their block sums fit (results do not depend on the cut);
+ *   - is shared by every context on that GPU and keeps the last call's contents (every entry a launch reads was
+ *     written by that launch, nothing needs clearing): calls that overlap on one GPU race — serialise them.
+ * The scene's device tables must be current: after changing the scene, the sky or the closest-hit structure call
+ * ir_render once (spp 0 is enough), else IR_ESTATE.  IR_SCHEDULE_WAVEFRONT and ir_enable_stats allocate: IR_ESTATE.
+ * Returns after enqueueing on the context's stream; ir_synchronize waits. */
+int ir_render_noalloc(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate, void* d_sum_rgba,
+                      void* d_counts);
 
 /* RayTracer::get_output (renderer.rs:164-169): resolve (mean, Reinhard, gamma 1/2.2, clamp, 0xAARRGGBB) on the
  * device and copy n = width*height u32 pixels to `out`.  Row 0 is the bottom row, as in the reference. */

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "ir_render": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "ir_render_async": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "ir_synchronize": (C.c_int, [ctx_p]),
+    "ir_render_noalloc": (C.c_int, [ctx_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "ir_get_output_argb": (C.c_int, [ctx_p, c_u32_p, C.c_size_t]),
     "ir_get_radiance": (C.c_int, [ctx_p, c_float_p, c_u32_p, C.c_size_t]),
     "ir_set_radiance": (C.c_int, [ctx_p, c_float_p, c_u32_p, C.c_size_t]),

@@ -764,6 +764,14 @@ int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t s
     return render_impl(ctx, width, height, spp, accumulate, nullptr, nullptr);
 }
 
+int ir_render_noalloc(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate, void* d_sum_rgba,
+                      void* d_counts) {
+    if (!ctx) return IR_EINVAL;
+    if (!d_sum_rgba || !d_counts) return fail(ctx, IR_EINVAL, "ir_render_noalloc: NULL output buffer");
+    if (((uintptr_t)d_sum_rgba & 15u) || ((uintptr_t)d_counts & 3u)) return fail(ctx, IR_EINVAL, "ir_render_noalloc: misaligned output buffer");
+    return render_impl(ctx, width, height, spp, accumulate, (float4*)d_sum_rgba, (uint32_t*)d_counts);
+}
+
 int ir_synchronize(ir_context* ctx) {
     if (!ctx) return IR_EINVAL;
     IR_TRY(use_device(ctx));
