@@ -239,12 +239,21 @@ class RayTracer:
                 _capi.check(ctx, _capi.lib.ir_set_skybox(ctx, None, 0, 0))
                 self._skybox_token = None
         else:
-            # the sky image is large; re-upload only when the ExrImage (or its buffer object) was replaced
-            token = (id(box), id(box.pixels_buffer), box.width, box.height, getattr(box, "version", 0))
-            if token != self._skybox_token:
-                buf = np.ascontiguousarray(box.pixels_buffer, dtype=np.float32)
+            # The sky image is large (6 MB at 1k, 400 MB at 8k): it is re-uploaded when the ExrImage or its buffer was
+            # replaced (identity against references held here, so a recycled id() cannot pass for the old object), when
+            # its size or `version` changed, or when a strided probe of the texels (1024 of them, first and last included)
+            # differs.  An in-place edit that misses every probed texel still needs `box.version += 1`.
+            buf_obj = box.pixels_buffer
+            flat = np.asarray(buf_obj).reshape(-1)
+            step = max(1, flat.shape[0] // 1024)
+            probe = flat[::step].tobytes() + flat[-1:].tobytes()
+            tok = self._skybox_token
+            same = (tok is not None and tok[0] is box and tok[1] is buf_obj and tok[2:5] == (box.width, box.height, getattr(box, "version", 0))
+                    and tok[5] == probe)
+            if not same:
+                buf = np.ascontiguousarray(buf_obj, dtype=np.float32)
                 _capi.check(ctx, _capi.lib.ir_set_skybox(ctx, _capi.fptr(buf), box.width, box.height))
-                self._skybox_token = token
+                self._skybox_token = (box, buf_obj, box.width, box.height, getattr(box, "version", 0), probe)
 
     def _upload_camera(self, width, height):
         cam = self.active_camera

@@ -199,3 +199,24 @@ def test_partial_scene_edits_keep_only_what_they_may(pta, tracer, oracle):
             tracer.set_accel(_capi.IR_ACCEL_AUTO)
     assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[1], frames[2]) and not np.array_equal(frames[2], frames[3])
     assert np.array_equal(frames[3], frames[4])
+
+
+def test_sky_edited_in_place_is_uploaded_again(pta, tracer, oracle):
+    """The reference reads the Scene afresh on every render (renderer.rs:122): a sky whose texels are edited in place
+    between two renders must show in the second one (the upload used to be keyed on id() alone)."""
+    from path_tracer_amd import workloads as W
+    w, h, spp = 64, 36, 4
+    scene = W.scene_s1()
+    cam = W.default_camera(w, h)
+    tracer.set_active_camera(cam)
+    tracer.set_integrator(bounces=5, max_compulsory_bounces=2, seed=7)
+    tracer.render(scene, w, h, False, spp=spp)
+    before, _ = tracer.get_radiance()
+    before = before.copy()
+    scene.skybox.pixels_buffer *= np.float32(0.25)  # same object, same buffer, new contents
+    tracer.render(scene, w, h, False, spp=spp)
+    after, _ = tracer.get_radiance()
+    ocam = oracle.camera_from(cam, w, h)
+    want, _, _, _ = oracle.render(ocam, scene, spp, bounces=5, rr_start=2, seed=7, math_mode=1)
+    assert np.array_equal(after.view(np.uint32), want.view(np.uint32))
+    assert not np.array_equal(after, before)
