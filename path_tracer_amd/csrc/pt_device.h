@@ -202,7 +202,16 @@ PT_DEV float atan2_poly(float y, float x) {
     } else if (ax == 0.0f) {
         a = 1.5707963267948966f;
     } else {
-        a = atan_pos(ay / ax);
+        float q;
+#if PT_FAST_MATH
+        // |x|, |y| of a (normalised) direction: ax in [2^-63, 2), ay == +0 or in [2^-36, 2) keeps the quotient in
+        // [2^-37, 2^64): div_seq's domain.  Anything else takes the IEEE divide, wave by wave.
+        if (__builtin_expect(wave_all(in_pow2_range<64, 128>(ax) && (f32_bits(ay) == 0u || in_pow2_range<91, 128>(ay))), 1))
+            q = div_seq(ay, ax, rcp_seq(ax));
+        else
+#endif
+            q = ay / ax;
+        a = atan_pos(q);
     }
     if (x < 0.0f) a = kPi - a;
     if (y < 0.0f) a = -a;
@@ -304,6 +313,9 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
         float disc = b * b - a4 * c;
         if (disc < 0.0f) continue;
         if (STATS) dp++;
+        // the root's numerator -b - sqrt(disc) can only be positive for b < 0 (sqrt >= 0; NaN and -0 compare false and
+        // would be rejected by num > 0 anyway): rays leaving a sphere they stand on skip its sqrt
+        if (!(b < 0.0f)) continue;
         const float num = -b - sqrt_cr(disc);
         if (num > 0.0f) {
             nsecond = __builtin_fminf(nsecond, __builtin_fmaxf(nmin, num));
@@ -434,6 +446,8 @@ PT_DEV void cursor_leaf_step(const LbvhView& v, LbvhCursor& c, const int* stack,
         float disc = b * b - c.a4 * cc;
         if (disc < 0.0f) continue;
         if (STATS) disc_pos++;
+        // t = (-b - sqrt(disc)) / 2a > 0 needs b < 0 (2a is >= 0, +inf or NaN; see trace_linear)
+        if (!(b < 0.0f)) continue;
         float sq = sqrt_cr(disc);
         float t = (-b - sq) / c.a2;
         const int orig = v.leaf_index[first + k];
