@@ -295,6 +295,11 @@ int ir_get_stats(ir_context* ctx, uint64_t out5[5]);
 /* Executed acceleration-structure work of the same render: LBVH node visits and leaf sphere tests (both 0 for the
  * linear scan).  The primary trace a pixel's samples share is counted once per launch here. */
 int ir_get_accel_stats(ir_context* ctx, uint64_t out2[2]);
+/* Lane activity of the same render, as 4 pairs (times a wave executed a section, lanes active in it); active lanes /
+ * (64 x wave executions) is the section's lane utilisation.  Linear-scan integrator: top of the path loop, Russian
+ * roulette (bounce >= max_compulsory_bounces), hit geometry, sky lookup + sample commit.  LBVH integrator: rounds of the
+ * wave loop (lanes with work left), shading block, inner-node steps, leaf steps. */
+int ir_get_lane_profile(ir_context* ctx, uint64_t out8[8]);
 
 /* Self test of the arithmetic contract (no counterpart in the reference).  The kernels replace hipcc's long IEEE
  * f32 sqrt / divide expansions by short sequences that return the same correctly rounded bits; this runs, on the

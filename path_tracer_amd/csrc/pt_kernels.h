@@ -54,7 +54,7 @@ struct RenderArgs {
 
     LbvhView bvh;  // used by the LBVH instantiation only
 
-    unsigned long long* stats;  // 7 counters or nullptr (only read by the STATS instantiation)
+    unsigned long long* stats;  // kNumStats counters or nullptr (only read by the STATS instantiation)
 };
 
 struct HitsArgs {
@@ -130,7 +130,7 @@ hipError_t launch_wavefront(const WfArgs& a, int accel, uint32_t per_batch, uint
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 enum { kAccelLinear = 0, kAccelLbvh = 1 };
-constexpr uint32_t kNumStats = 7;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests
+constexpr uint32_t kNumStats = 15;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests, 8 x lane profile
 hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream);
 hipError_t launch_resolve(const float4* sum, const uint32_t* counts, uint32_t* argb, size_t n, hipStream_t stream);

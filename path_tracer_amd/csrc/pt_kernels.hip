@@ -55,6 +55,16 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
     // per-lane work statistics (STATS only): traces, discriminant >= 0 tests, hits
     uint32_t n_traces = 0, n_disc = 0, n_hits = 0;
     WorkCounters wc0 = {0, 0, 0}, wc = {0, 0, 0};
+    // lane-activity profile (STATS only): for the loop top and its three lane-dependent sections, how many times a wave
+    // ran the section (counted on its first active lane) and how many lanes were active in it
+    uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto profile = [&](int section) {
+        if constexpr (STATS) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+            prof[2 * section] += (uint32_t)(__builtin_ctzll(m) == (int)(threadIdx.x & 63u));
+            prof[2 * section + 1] += 1u;
+        }
+    };
 
     // ---- primary ray + primary closest hit (shared by all samples of the pixel)
     Ray r0;
@@ -111,6 +121,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
             const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
 
             while (s < spp) {
+                profile(0);
                 // ---- shade the hit of bounce b (integrator.rs:50-81)
                 const float4 m_brdf = a.shade[2 * idx];
                 const float4 m_emit = a.shade[2 * idx + 1];
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
                 contrib = contrib * scatter_weight(mk3(m_brdf.x, m_brdf.y, m_brdf.z), cos_theta, fast);
                 bool done = false;
                 if (b >= R) {
+                    profile(1);
                     const float p = __builtin_fmaxf(contrib.x, __builtin_fmaxf(contrib.y, contrib.z));
                     if (draw(skey, 3 * b + 2) > p) {
                         done = true;
@@ -167,11 +179,13 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
                         const HitRec h = trace_any<ACCEL, STATS>(a, s_sph, o, d, wc);
                         if (STATS) { n_traces++; n_disc += wc.disc - before; }
                         if (h.idx >= 0) {
+                            profile(2);
                             if (STATS) n_hits++;
                             const float4 sp = sphere_at<ACCEL>(a, s_sph, h.idx);
                             hit_geometry(sp, o, d, h.t, pos, nrm);
                             idx = h.idx;
                         } else {
+                            profile(3);
                             if constexpr (SKYMIS) {
                                 size_t texel;
                                 float sin_polar;
@@ -219,6 +233,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
         // executed acceleration-structure work (the shared primary trace is counted once per launch)
         atomicAdd(&a.stats[5], (unsigned long long)wc.nodes + wc0.nodes);
         atomicAdd(&a.stats[6], (unsigned long long)wc.leaves + wc0.leaves);
+        for (int k = 0; k < 8; ++k)
+            if (prof[k]) atomicAdd(&a.stats[7 + k], (unsigned long long)prof[k]);
     }
 }
 
@@ -237,16 +253,39 @@ constexpr uint32_t kStepsPerRound = 8; // traversal steps between two looks at t
 
 // SKYMIS (sky importance sampling, see render_kernel): the shadow ray is one more traversal of the lane's state machine,
 // run before the bounce ray, which waits in registers (direction, density, the strategy's weighted sky term).
-template <bool STATS, bool SKYMIS>
+// COMPACT: bounce rays walk the 32-byte nodes (pt_device.h "Compact inner node"), the top levels out of an LDS copy; the
+// primary ray, traced once per pixel and block, stays on the wide nodes.
+template <bool STATS, bool SKYMIS, bool COMPACT>
 __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const RenderArgs a) {
-    extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
+    extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]; then the treelet
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
+    const uint4* const s_tree = reinterpret_cast<const uint4*>(s_dyn) + (size_t)a.bvh.stack_depth * 64;
+    if constexpr (COMPACT) {
+        uint4* const dst = reinterpret_cast<uint4*>(s_dyn) + (size_t)a.bvh.stack_depth * 64;
+        for (uint32_t i = threadIdx.x; i < 2 * a.bvh.treelet_nodes; i += 256) dst[i] = a.bvh.treelet[i];
+        __syncthreads();
+    }
+    const int root = (COMPACT && a.bvh.treelet_nodes) ? kTreeletTag : 0;
+    auto inner_step = [&](LbvhCursor& c, uint32_t& visits) {
+        if constexpr (COMPACT) cursor_inner_step_compact<STATS>(a.bvh, s_tree, c, stack, 256u, visits);
+        else cursor_inner_step<STATS>(a.bvh, c, stack, 256u, visits);
+    };
     const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
     uint32_t x, y;
     if (!lane_pixel(wg, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
     const uint32_t pixel = y * a.w + x;
     uint32_t n_traces = 0, n_disc = 0, n_hits = 0;
     WorkCounters wc0 = {0, 0, 0}, wc = {0, 0, 0};
+    // lane-activity profile (STATS only; ir_get_lane_profile): rounds of the wave loop (lanes with work left), shading
+    // block, inner-node steps, leaf steps — wave executions (counted on the first active lane) and active lanes
+    uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto profile = [&](int section) {
+        if constexpr (STATS) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+            prof[2 * section] += (uint32_t)(__builtin_ctzll(m) == (int)(threadIdx.x & 63u));
+            prof[2 * section + 1] += 1u;
+        }
+    };
 
     Ray r0;
     if (a.rays) {
@@ -304,15 +343,17 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
         const uint32_t n_wait = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(waiting));
         const uint32_t n_trav = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(traversing));
         if (n_wait == 0 && n_trav == 0) break;
+        if (waiting || traversing) profile(0);
         if (n_wait >= kShadeBatch || n_trav == 0) {
             if (waiting) {
+                profile(1);
                 if (landed) {  // consume the finished traversal (integrator.rs:50-51, 82-90)
                     landed = false;
                     if (STATS) { n_traces++; }
                     if (SKYMIS && shadow) {
                         if (cur.idx < 0) light = light + sky_term;
                         shadow = false;
-                        cursor_begin(cur, pos + nrm * kEps, wi_next);
+                        cursor_begin(cur, pos + nrm * kEps, wi_next, root);
                         traversing = true;
                     } else if (cur.idx >= 0) {
                         if (STATS) n_hits++;
@@ -386,12 +427,12 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
                                     sky_term = (sk * contrib) * (pa / (pe + pa));
                                     wi_next = wi;
                                     shadow = true;
-                                    cursor_begin(cur, pos + nrm * kEps, ws);
+                                    cursor_begin(cur, pos + nrm * kEps, ws, root);
                                     traversing = true;
                                     break;
                                 }
                             }
-                            cursor_begin(cur, pos + nrm * kEps, wi);
+                            cursor_begin(cur, pos + nrm * kEps, wi, root);
                             traversing = true;
                             break;
                         }
@@ -405,9 +446,9 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
         // node steps or a majority vote between the two kinds of step measured no better).
         for (uint32_t k = 0; k < kStepsPerRound; ++k) {
             if (traversing) {
-                if (cur.cur >= 0) cursor_inner_step<STATS>(a.bvh, cur, stack, 256u, wc.nodes);
-                if (cur.cur >= 0 && cur.cur != kCursorDone) cursor_inner_step<STATS>(a.bvh, cur, stack, 256u, wc.nodes);
-                if (cur.cur < 0) cursor_leaf_step<STATS>(a.bvh, cur, stack, 256u, wc.disc, wc.leaves);
+                if (cur.cur >= 0) { profile(2); inner_step(cur, wc.nodes); }
+                if (cur.cur >= 0 && cur.cur != kCursorDone) { profile(2); inner_step(cur, wc.nodes); }
+                if (cur.cur < 0) { profile(3); cursor_leaf_step<STATS>(a.bvh, cur, stack, 256u, wc.disc, wc.leaves); }
                 if (cur.cur == kCursorDone) {
                     traversing = false;
                     landed = true;
@@ -433,6 +474,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
         atomicAdd(&a.stats[4], (unsigned long long)n_hits);
         atomicAdd(&a.stats[5], (unsigned long long)wc.nodes + wc0.nodes);
         atomicAdd(&a.stats[6], (unsigned long long)wc.leaves + wc0.leaves);
+        for (int k = 0; k < 8; ++k)
+            if (prof[k]) atomicAdd(&a.stats[7 + k], (unsigned long long)prof[k]);
     }
 }
 
@@ -527,14 +570,23 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     if (a.n_blocks == 1) a.partials = nullptr;  // single block: the kernel merges into the accumulator itself
     const dim3 grid(a.wgs_per_layer * a.n_blocks), block(256);
     if (accel == kAccelLbvh) {
-        const size_t lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int);
+        // experiments only (tools/): IR_DEBUG_WIDE_NODES=1 keeps the 64-byte nodes, IR_DEBUG_NO_TREELET=1 the LDS treelet out
+        static const bool force_wide = getenv("IR_DEBUG_WIDE_NODES") != nullptr, no_treelet = getenv("IR_DEBUG_NO_TREELET") != nullptr;
+        if (force_wide) a.bvh.compact = nullptr;
+        if (no_treelet || !a.bvh.compact) a.bvh.treelet_nodes = 0;
+        const bool compact = a.bvh.compact != nullptr;
+        const size_t lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int) + (compact ? (size_t)a.bvh.treelet_nodes * 32 : 0);
         const bool skymis = a.sky_marginal != nullptr;
-        if (stats) {
-            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<true, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((render_lbvh_kernel<true, false>), grid, block, lds, stream, a);
-        } else {
-            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<false, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((render_lbvh_kernel<false, false>), grid, block, lds, stream, a);
+        const int variant = (stats ? 4 : 0) | (skymis ? 2 : 0) | (compact ? 1 : 0);
+        switch (variant) {
+            case 0: hipLaunchKernelGGL((render_lbvh_kernel<false, false, false>), grid, block, lds, stream, a); break;
+            case 1: hipLaunchKernelGGL((render_lbvh_kernel<false, false, true>), grid, block, lds, stream, a); break;
+            case 2: hipLaunchKernelGGL((render_lbvh_kernel<false, true, false>), grid, block, lds, stream, a); break;
+            case 3: hipLaunchKernelGGL((render_lbvh_kernel<false, true, true>), grid, block, lds, stream, a); break;
+            case 4: hipLaunchKernelGGL((render_lbvh_kernel<true, false, false>), grid, block, lds, stream, a); break;
+            case 5: hipLaunchKernelGGL((render_lbvh_kernel<true, false, true>), grid, block, lds, stream, a); break;
+            case 6: hipLaunchKernelGGL((render_lbvh_kernel<true, true, false>), grid, block, lds, stream, a); break;
+            default: hipLaunchKernelGGL((render_lbvh_kernel<true, true, true>), grid, block, lds, stream, a); break;
         }
     } else {
         size_t lds = (size_t)a.n_spheres * sizeof(float4);

@@ -196,6 +196,13 @@ class RayTracer:
         _capi.check(self._ctx, _capi.lib.ir_get_accel_stats(self._ctx, out))
         return {"bvh_node_visits": int(out[0]), "bvh_leaf_tests": int(out[1])}
 
+    def get_lane_profile(self):
+        """(wave executions, active lanes) of the path loop's top, roulette, hit-geometry and sky/commit sections."""
+        out = (C.c_uint64 * 8)()
+        _capi.check(self._ctx, _capi.lib.ir_get_lane_profile(self._ctx, out))
+        v = [int(x) for x in out]
+        return {k: (v[2 * i], v[2 * i + 1]) for i, k in enumerate(("loop", "roulette", "hit", "sky"))}
+
     def last_kernel_ms(self):
         n = C.c_uint32()
         ms = _capi.lib.ir_last_kernel_ms(self._ctx, C.byref(n))
