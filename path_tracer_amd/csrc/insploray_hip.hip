@@ -208,38 +208,6 @@ int build_bvh_device(ir_context* ctx, bool* too_deep) {
     return IR_OK;
 }
 
-// Compact nodes + treelet from the wide nodes just built (either builder, or a refit).  root: the root wide node on the
-// host, or nullptr to fetch it from the device.  Failing to qualify is not an error: the integrator keeps the wide nodes.
-int finish_bvh_compact(ir_context* ctx, const float* root) {
-    ctx->bvh_compact_ok = false;
-    ctx->bvh_treelet_nodes = 0;
-    if (ctx->bvh_nodes == 0) return IR_OK;
-    float fetched[16];
-    if (!root) {
-        IR_HIP(ctx, hipMemcpyAsync(fetched, ctx->d_bvh_nodes.p, sizeof(fetched), hipMemcpyDeviceToHost, ctx->stream));
-        IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        root = fetched;
-    }
-    pt::LbvhGrid g;
-    if (!pt::lbvh_grid_from_root(root, &g)) return IR_OK;
-    IR_TRY(ensure(ctx, ctx->d_bvh_compact, (size_t)ctx->bvh_nodes * 32));
-    IR_TRY(ensure(ctx, ctx->d_bvh_treelet, (size_t)pt::kTreeletMaxNodes * 32));
-    IR_TRY(ensure(ctx, ctx->d_bvh_flags, 2 * sizeof(uint32_t)));
-    IR_HIP(ctx, pt::lbvh_compact_device((const float4*)ctx->d_bvh_nodes.p, ctx->bvh_nodes, g, (uint4*)ctx->d_bvh_compact.p,
-                                        (uint4*)ctx->d_bvh_treelet.p, (uint32_t*)ctx->d_bvh_flags.p, ctx->stream));
-    uint32_t flags[2] = {1u, 0u};
-    IR_HIP(ctx, hipMemcpyAsync(flags, ctx->d_bvh_flags.p, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (flags[0] != 0u || flags[1] > pt::kTreeletMaxNodes) return IR_OK;
-    ctx->bvh_compact_ok = true;
-    ctx->bvh_treelet_nodes = flags[1];
-    for (int k = 0; k < 3; ++k) {
-        ctx->bvh_grid[k] = g.base[k];
-        ctx->bvh_grid[3 + k] = g.step[k];
-    }
-    return IR_OK;
-}
-
 int ensure_bvh(ir_context* ctx) {
     if (selected_accel(ctx) != pt::kAccelLbvh || ctx->bvh_valid) return IR_OK;
     const auto t0 = std::chrono::steady_clock::now();
@@ -253,7 +221,6 @@ int ensure_bvh(ir_context* ctx) {
         on_device = !too_deep;
     }
     if (!on_device) IR_TRY(build_bvh_host(ctx));
-    IR_TRY(finish_bvh_compact(ctx, nullptr));
     ctx->bvh_build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ctx->bvh_valid = true;
     return IR_OK;
@@ -283,13 +250,6 @@ void fill_bvh(const ir_context* ctx, pt::LbvhView& v) {
     v.leaf_spheres = (const float4*)ctx->d_bvh_spheres.p;
     v.leaf_index = (const int*)ctx->d_bvh_index.p;
     v.stack_depth = ctx->bvh_stack;
-    v.compact = ctx->bvh_compact_ok ? (const uint4*)ctx->d_bvh_compact.p : nullptr;
-    v.treelet = ctx->bvh_compact_ok ? (const uint4*)ctx->d_bvh_treelet.p : nullptr;
-    v.treelet_nodes = ctx->bvh_compact_ok ? ctx->bvh_treelet_nodes : 0;
-    for (int k = 0; k < 3; ++k) {
-        v.base[k] = ctx->bvh_grid[k];
-        v.step[k] = ctx->bvh_grid[3 + k];
-    }
 }
 
 void fill_camera(const ir_context* ctx, pt::CameraBlock& c) {
@@ -382,7 +342,6 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_wf_queue[0]); release(ctx->d_wf_queue[1]); release(ctx->d_wf_counts); release(ctx->d_wf_values);
     release(ctx->d_wf_prim); release(ctx->d_wf_tileacc);
     release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index); release(ctx->d_bvh_scratch);
-    release(ctx->d_bvh_compact); release(ctx->d_bvh_treelet); release(ctx->d_bvh_flags);
     release(ctx->d_sky_marginal); release(ctx->d_sky_cond); release(ctx->d_sky_pdf);
     release(ctx->d_sky_marginal_guide); release(ctx->d_sky_cond_guide);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

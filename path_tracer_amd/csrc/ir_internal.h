@@ -39,10 +39,6 @@ struct ir_context {
     irx::DeviceBuf d_spheres, d_shade;
     // LBVH (built before the first launch that needs it, on the host or on the device: ir_set_accel_build)
     irx::DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index, d_bvh_scratch;
-    irx::DeviceBuf d_bvh_compact, d_bvh_treelet, d_bvh_flags;  // 32-byte nodes + LDS treelet (pt_lbvh_compact.hip)
-    bool bvh_compact_ok = false;
-    uint32_t bvh_treelet_nodes = 0;
-    float bvh_grid[6] = {0, 0, 0, 0, 0, 0};  // base xyz, step xyz
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_stack = 0;
     bool bvh_valid = false;
     int bvh_build = IR_BUILD_AUTO;

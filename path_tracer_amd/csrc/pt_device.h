@@ -362,30 +362,7 @@ struct LbvhView {
     const float4* __restrict__ leaf_spheres;  // leaf order: (cx, cy, cz, r*r)
     const int* __restrict__ leaf_index;       // leaf order -> original sphere index
     uint32_t stack_depth;                     // entries a traversal may need (<= kMaxStack)
-    // Compact nodes (pt_lbvh_compact.hip; nullptr when the tree cannot be quantised): the same tree, 32 bytes per inner
-    // node, boxes on a 16-bit grid over the root box, rounded outwards.  See CompactNode below.
-    const uint4* __restrict__ compact;        // 2 x uint4 per inner node, same node numbering as `wide`
-    const uint4* __restrict__ treelet;        // the top levels in breadth-first order, child refs tagged (kTreeletTag)
-    uint32_t treelet_nodes;                   // 0 = none
-    float base[3], step[3];                   // grid: coordinate = base + q * step
 };
-
-// ----------------------------------------------------------------------------------------------------
-// Compact inner node: 32 bytes instead of 64, so that a traversal step is two 16-byte loads per lane instead of four
-// (the LBVH integrator is bound by the vector-memory return path, TD busy 86 %, not by VALU issue).
-//   a = (l.lo.x | l.lo.y << 16,  l.lo.z | l.hi.x << 16,  l.hi.y | l.hi.z << 16,  r.lo.x | r.lo.y << 16)
-//   b = (r.lo.z | r.hi.x << 16,  r.hi.y | r.hi.z << 16,  left ref,  right ref)
-// A 16-bit value q stands for base + q * step on its axis; the builder rounds every lo down and every hi up by one
-// further step, so the decoded box CONTAINS the f32 box of the wide node.  Node tests only have to be conservative (the
-// leaf tests decide (t, index), lbvh.h), and a larger box is: results are the wide tree's, a few more nodes are visited.
-// The traversal never forms base + q * step: it evaluates q * step - (o - base), whose rounding errors (2^-24 of the
-// grid extent and of |o - base|) are covered by the spare step of the builder's rounding close to the scene and by the
-// box pad (2^-7 of the distance, see padded_box_hit) far from it.
-// Treelet: the top levels copied breadth-first into LDS by the integrator; refs to nodes inside it are kTreeletTag | slot.
-// ----------------------------------------------------------------------------------------------------
-constexpr int kTreeletTag = 0x40000000;
-constexpr uint32_t kTreeletLevels = 8;
-constexpr uint32_t kTreeletMaxNodes = (1u << kTreeletLevels) - 1u;  // 255 nodes = 8160 bytes
 
 // Traversal state of one ray.  A traversal is cursor_begin + cursor_step until cur == kCursorDone: the integrator's
 // LBVH kernel interleaves steps of different lanes' rays with shading (render_lbvh_kernel), trace_lbvh runs one to
@@ -399,7 +376,7 @@ struct LbvhCursor {
     int cur;       // >= 0: inner node, < 0: leaf -(first * 8 + count) - 1, kCursorDone: finished
     uint32_t sp;   // stack entries in use
 };
-PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d, int root = 0) {
+PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
     c.o = o;
     c.d = d;
     const float a = dot(d, d);
@@ -410,11 +387,12 @@ PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d, int root = 0) {
     c.iz = 1.0f / d.z;
     c.best = kF32Max;
     c.idx = -1;
-    c.cur = root;
+    c.cur = 0;
     c.sp = 0;
 }
-// box given relative to the ray origin: (lx, ly, lz) = lo - o, (hx, hy, hz) = hi - o
-PT_DEV bool padded_box_hit_rel(const LbvhCursor& c, float lx, float ly, float lz, float hx, float hy, float hz, float& tmin) {
+PT_DEV bool padded_box_hit(const LbvhCursor& c, float4 lo, float4 hi, float& tmin) {
+    const float lx = lo.x - c.o.x, ly = lo.y - c.o.y, lz = lo.z - c.o.z;
+    const float hx = hi.x - c.o.x, hy = hi.y - c.o.y, hz = hi.z - c.o.z;
     const float pad = (__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)) + __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy)) +
                        __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * 0.0078125f;
     const float t1x = (lx - pad) * c.ix, t2x = (hx + pad) * c.ix;
@@ -424,9 +402,6 @@ PT_DEV bool padded_box_hit_rel(const LbvhCursor& c, float lx, float ly, float lz
     tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
     const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
     return (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= c.best);
-}
-PT_DEV bool padded_box_hit(const LbvhCursor& c, float4 lo, float4 hi, float& tmin) {
-    return padded_box_hit_rel(c, lo.x - c.o.x, lo.y - c.o.y, lo.z - c.o.z, hi.x - c.o.x, hi.y - c.o.y, hi.z - c.o.z, tmin);
 }
 PT_DEV int cursor_pop(LbvhCursor& c, const int* stack, uint32_t stride) {
     if (c.sp == 0) return kCursorDone;
@@ -443,45 +418,6 @@ PT_DEV void cursor_inner_step(const LbvhView& v, LbvhCursor& c, int* stack, uint
     float tl, tr;
     const bool hl = padded_box_hit(c, n0, n1, tl), hr = padded_box_hit(c, n2, n3, tr);
     const int rl = __builtin_bit_cast(int, n0.w), rr = __builtin_bit_cast(int, n1.w);
-    if (hl && hr) {
-        const bool right_first = tr < tl;
-        stack[c.sp * stride] = right_first ? rl : rr;
-        c.sp++;
-        c.cur = right_first ? rr : rl;
-    } else if (hl) {
-        c.cur = rl;
-    } else if (hr) {
-        c.cur = rr;
-    } else {
-        c.cur = cursor_pop(c, stack, stride);
-    }
-}
-// The same step over compact nodes.  c.cur >= kTreeletTag: the node sits in the LDS copy of the top levels (`lds_tree`),
-// otherwise in v.compact.  Precondition: c.cur >= 0 and c.cur != kCursorDone.
-PT_DEV float grid_lo(uint32_t word, float step, float orel) { return (float)(word & 0xffffu) * step - orel; }
-PT_DEV float grid_hi(uint32_t word, float step, float orel) { return (float)(word >> 16) * step - orel; }
-template <bool STATS>
-PT_DEV void cursor_inner_step_compact(const LbvhView& v, const uint4* lds_tree, LbvhCursor& c, int* stack, uint32_t stride,
-                                      uint32_t& node_visits) {
-    uint4 a, b;
-    if (c.cur >= kTreeletTag) {
-        const uint32_t at = 2u * (uint32_t)(c.cur - kTreeletTag);
-        a = lds_tree[at];
-        b = lds_tree[at + 1];
-    } else {
-        const size_t at = 2 * (size_t)c.cur;
-        a = v.compact[at];
-        b = v.compact[at + 1];
-    }
-    if (STATS) node_visits += 2;
-    const float ox = c.o.x - v.base[0], oy = c.o.y - v.base[1], oz = c.o.z - v.base[2];
-    const float sx = v.step[0], sy = v.step[1], sz = v.step[2];
-    float tl, tr;
-    const bool hl = padded_box_hit_rel(c, grid_lo(a.x, sx, ox), grid_hi(a.x, sy, oy), grid_lo(a.y, sz, oz), grid_hi(a.y, sx, ox),
-                                       grid_lo(a.z, sy, oy), grid_hi(a.z, sz, oz), tl);
-    const bool hr = padded_box_hit_rel(c, grid_lo(a.w, sx, ox), grid_hi(a.w, sy, oy), grid_lo(b.x, sz, oz), grid_hi(b.x, sx, ox),
-                                       grid_lo(b.y, sy, oy), grid_hi(b.y, sz, oz), tr);
-    const int rl = (int)b.z, rr = (int)b.w;
     if (hl && hr) {
         const bool right_first = tr < tl;
         stack[c.sp * stride] = right_first ? rl : rr;

@@ -253,23 +253,10 @@ constexpr uint32_t kStepsPerRound = 8; // traversal steps between two looks at t
 
 // SKYMIS (sky importance sampling, see render_kernel): the shadow ray is one more traversal of the lane's state machine,
 // run before the bounce ray, which waits in registers (direction, density, the strategy's weighted sky term).
-// COMPACT: bounce rays walk the 32-byte nodes (pt_device.h "Compact inner node"), the top levels out of an LDS copy; the
-// primary ray, traced once per pixel and block, stays on the wide nodes.
-template <bool STATS, bool SKYMIS, bool COMPACT>
+template <bool STATS, bool SKYMIS>
 __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const RenderArgs a) {
-    extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]; then the treelet
+    extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
-    const uint4* const s_tree = reinterpret_cast<const uint4*>(s_dyn) + (size_t)a.bvh.stack_depth * 64;
-    if constexpr (COMPACT) {
-        uint4* const dst = reinterpret_cast<uint4*>(s_dyn) + (size_t)a.bvh.stack_depth * 64;
-        for (uint32_t i = threadIdx.x; i < 2 * a.bvh.treelet_nodes; i += 256) dst[i] = a.bvh.treelet[i];
-        __syncthreads();
-    }
-    const int root = (COMPACT && a.bvh.treelet_nodes) ? kTreeletTag : 0;
-    auto inner_step = [&](LbvhCursor& c, uint32_t& visits) {
-        if constexpr (COMPACT) cursor_inner_step_compact<STATS>(a.bvh, s_tree, c, stack, 256u, visits);
-        else cursor_inner_step<STATS>(a.bvh, c, stack, 256u, visits);
-    };
     const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
     uint32_t x, y;
     if (!lane_pixel(wg, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
@@ -353,7 +340,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
                     if (SKYMIS && shadow) {
                         if (cur.idx < 0) light = light + sky_term;
                         shadow = false;
-                        cursor_begin(cur, pos + nrm * kEps, wi_next, root);
+                        cursor_begin(cur, pos + nrm * kEps, wi_next);
                         traversing = true;
                     } else if (cur.idx >= 0) {
                         if (STATS) n_hits++;
@@ -427,12 +414,12 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
                                     sky_term = (sk * contrib) * (pa / (pe + pa));
                                     wi_next = wi;
                                     shadow = true;
-                                    cursor_begin(cur, pos + nrm * kEps, ws, root);
+                                    cursor_begin(cur, pos + nrm * kEps, ws);
                                     traversing = true;
                                     break;
                                 }
                             }
-                            cursor_begin(cur, pos + nrm * kEps, wi, root);
+                            cursor_begin(cur, pos + nrm * kEps, wi);
                             traversing = true;
                             break;
                         }
@@ -446,8 +433,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
         // node steps or a majority vote between the two kinds of step measured no better).
         for (uint32_t k = 0; k < kStepsPerRound; ++k) {
             if (traversing) {
-                if (cur.cur >= 0) { profile(2); inner_step(cur, wc.nodes); }
-                if (cur.cur >= 0 && cur.cur != kCursorDone) { profile(2); inner_step(cur, wc.nodes); }
+                if (cur.cur >= 0) { profile(2); cursor_inner_step<STATS>(a.bvh, cur, stack, 256u, wc.nodes); }
+                if (cur.cur >= 0 && cur.cur != kCursorDone) { profile(2); cursor_inner_step<STATS>(a.bvh, cur, stack, 256u, wc.nodes); }
                 if (cur.cur < 0) { profile(3); cursor_leaf_step<STATS>(a.bvh, cur, stack, 256u, wc.disc, wc.leaves); }
                 if (cur.cur == kCursorDone) {
                     traversing = false;
@@ -570,23 +557,14 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     if (a.n_blocks == 1) a.partials = nullptr;  // single block: the kernel merges into the accumulator itself
     const dim3 grid(a.wgs_per_layer * a.n_blocks), block(256);
     if (accel == kAccelLbvh) {
-        // experiments only (tools/): IR_DEBUG_WIDE_NODES=1 keeps the 64-byte nodes, IR_DEBUG_NO_TREELET=1 the LDS treelet out
-        static const bool force_wide = getenv("IR_DEBUG_WIDE_NODES") != nullptr, no_treelet = getenv("IR_DEBUG_NO_TREELET") != nullptr;
-        if (force_wide) a.bvh.compact = nullptr;
-        if (no_treelet || !a.bvh.compact) a.bvh.treelet_nodes = 0;
-        const bool compact = a.bvh.compact != nullptr;
-        const size_t lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int) + (compact ? (size_t)a.bvh.treelet_nodes * 32 : 0);
+        const size_t lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int);
         const bool skymis = a.sky_marginal != nullptr;
-        const int variant = (stats ? 4 : 0) | (skymis ? 2 : 0) | (compact ? 1 : 0);
-        switch (variant) {
-            case 0: hipLaunchKernelGGL((render_lbvh_kernel<false, false, false>), grid, block, lds, stream, a); break;
-            case 1: hipLaunchKernelGGL((render_lbvh_kernel<false, false, true>), grid, block, lds, stream, a); break;
-            case 2: hipLaunchKernelGGL((render_lbvh_kernel<false, true, false>), grid, block, lds, stream, a); break;
-            case 3: hipLaunchKernelGGL((render_lbvh_kernel<false, true, true>), grid, block, lds, stream, a); break;
-            case 4: hipLaunchKernelGGL((render_lbvh_kernel<true, false, false>), grid, block, lds, stream, a); break;
-            case 5: hipLaunchKernelGGL((render_lbvh_kernel<true, false, true>), grid, block, lds, stream, a); break;
-            case 6: hipLaunchKernelGGL((render_lbvh_kernel<true, true, false>), grid, block, lds, stream, a); break;
-            default: hipLaunchKernelGGL((render_lbvh_kernel<true, true, true>), grid, block, lds, stream, a); break;
+        if (stats) {
+            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<true, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((render_lbvh_kernel<true, false>), grid, block, lds, stream, a);
+        } else {
+            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<false, true>), grid, block, lds, stream, a);
+            else hipLaunchKernelGGL((render_lbvh_kernel<false, false>), grid, block, lds, stream, a);
         }
     } else {
         size_t lds = (size_t)a.n_spheres * sizeof(float4);

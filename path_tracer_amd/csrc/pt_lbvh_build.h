@@ -30,16 +30,4 @@ hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch,
 // Wide nodes in pre-order into d_wide (room for n - 1 nodes of 64 bytes); fills info[6] and info[7].
 hipError_t lbvh_emit_device(const float4* d_spheres, uint32_t n, const LbvhDeviceTree& tree, float4* d_wide, hipStream_t stream);
 
-// ---- compact nodes and treelet (pt_lbvh_compact.hip; layout in pt_device.h)
-struct LbvhGrid {
-    float base[3], step[3];
-};
-// Grid over the root box of the tree whose root wide node (16 floats) is given; false when the box is not finite or sits
-// too far from the origin for its size (the integrator then keeps the 64-byte nodes).
-bool lbvh_grid_from_root(const float root_node[16], LbvhGrid* g);
-// d_compact: 2 x uint4 per node; d_treelet: 2 x uint4 x kTreeletMaxNodes; d_flags: uint32[2] = {a coordinate was not
-// finite (compact nodes unusable), treelet node count}, valid once the stream has drained.
-hipError_t lbvh_compact_device(const float4* d_wide, uint32_t n_nodes, const LbvhGrid& g, uint4* d_compact, uint4* d_treelet,
-                               uint32_t* d_flags, hipStream_t stream);
-
 }  // namespace pt
