@@ -140,10 +140,13 @@ uint32_t auto_sample_block(uint32_t wgs_per_block, uint32_t spp) {
     return sb;
 }
 
-// Scratch of ir_render_noalloc: the block sums of one launch (what ir_render keeps in a hipMalloc'ed buffer).  One copy
+// Scratch of ir_render_noalloc: the launch scratch (primary-pass records, task list, the block sums of one launch: what
+// ir_render keeps in hipMalloc'ed buffers).  One copy
 // per GPU the library runs on, held until the process ends.  Host code never passes this NAME to a kernel or a memset:
 // ir_create asks each device for ITS copy's address (hipGetSymbolAddress) and keeps it in g_noalloc_scratch[device].
-constexpr size_t kNoAllocScratchBytes = 128ull << 20;
+constexpr size_t kNoAllocScratchBytes = 160ull << 20;
+// per pixel: primary record 32 B + task list entry 4 B + two block sums of 16 B (a launch of at least two blocks)
+constexpr size_t kNoAllocMaxPixels = (kNoAllocScratchBytes - 4096) / (pt::kPrimBytesPerPixel + pt::kTaskBytesPerPixel + 2 * sizeof(float4));
 __device__ __align__(256) float4 g_noalloc_scratch_array[kNoAllocScratchBytes / sizeof(float4)];
 constexpr int kMaxDevices = 64;
 void* g_noalloc_scratch[kMaxDevices] = {nullptr};
@@ -339,6 +342,7 @@ void ir_destroy(ir_context* ctx) {
     if (ctx->h_argb) (void)hipHostFree(ctx->h_argb);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
     release(ctx->d_stats); release(ctx->d_partials);
+    release(ctx->d_prim); release(ctx->d_task_pixels); release(ctx->d_task_counters);
     release(ctx->d_wf_queue[0]); release(ctx->d_wf_queue[1]); release(ctx->d_wf_counts); release(ctx->d_wf_values);
     release(ctx->d_wf_prim); release(ctx->d_wf_tileacc);
     release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index); release(ctx->d_bvh_scratch);
@@ -587,9 +591,9 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     uint32_t* const counts = noalloc ? ext_counts : film_counts(ctx);
     if (noalloc) {
         // before anything is enqueued: a frame whose block sums do not fit the static scratch is refused outright
-        if (n > kNoAllocScratchBytes / (2 * sizeof(float4)))
-            return fail(ctx, IR_ELIMIT, "%s: %ux%u pixels exceed the %zu the %zu MiB static scratch holds two block sums for", who,
-                        width, height, kNoAllocScratchBytes / (2 * sizeof(float4)), kNoAllocScratchBytes >> 20);
+        if (n > kNoAllocMaxPixels)
+            return fail(ctx, IR_ELIMIT, "%s: %ux%u pixels exceed the %zu the %zu MiB static scratch holds the launch scratch for", who,
+                        width, height, kNoAllocMaxPixels, kNoAllocScratchBytes >> 20);
         if (ctx->schedule == IR_SCHEDULE_WAVEFRONT)
             return fail(ctx, IR_ESTATE, "%s: the wavefront schedule allocates its path queues; select IR_SCHEDULE_AUTO/REGENERATION", who);
         if (ctx->stats_enabled) return fail(ctx, IR_ESTATE, "%s: statistics need an allocated counter buffer; use ir_render", who);
@@ -722,18 +726,35 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     chunk = chunk < sb ? sb : chunk / sb * sb;
     // ... and bound the block sums of one launch (16 B per pixel and block): more launches rather than more memory.  A
     // small sample_block is what a caller sets to get the reference's per-sample sum order; it must not cost 100 GB.
-    const size_t partials_budget = noalloc ? kNoAllocScratchBytes : kPartialsBudgetBytes;
+    // The launch also needs the primary-pass records and the task list (36 B per pixel + counters).
+    const size_t fixed_bytes = n * (pt::kPrimBytesPerPixel + pt::kTaskBytesPerPixel) + 2 * pt::kTaskCounterBytes;
+    const size_t partials_budget = noalloc ? kNoAllocScratchBytes - fixed_bytes : kPartialsBudgetBytes;
     size_t budget_blocks = partials_budget / (n * sizeof(float4));
     if (budget_blocks < 2) budget_blocks = 2;  // (ir_render_noalloc refused such a frame above)
     if ((size_t)chunk / sb > budget_blocks) chunk = (uint32_t)budget_blocks * sb;
     const uint32_t max_blocks = ((spp < chunk ? spp : chunk) + sb - 1) / sb;
+    if ((uint64_t)n * max_blocks > 0xffffffffull) return fail(ctx, IR_ELIMIT, "%s: too many tasks in one launch", who);
     a.sample_block = sb;
     if (noalloc) {
-        a.partials = (ctx->device < kMaxDevices) ? (float4*)g_noalloc_scratch[ctx->device] : nullptr;
-        if (!a.partials) return fail(ctx, IR_ESTATE, "%s: no static scratch on device %d", who, ctx->device);
+        // carve the static array: records | task list | counters | block sums
+        char* base = (ctx->device < kMaxDevices) ? (char*)g_noalloc_scratch[ctx->device] : nullptr;
+        if (!base) return fail(ctx, IR_ESTATE, "%s: no static scratch on device %d", who, ctx->device);
+        a.prim = (float4*)base;
+        size_t off = n * pt::kPrimBytesPerPixel;
+        a.task_pixels = (uint32_t*)(base + off);
+        off = (off + n * pt::kTaskBytesPerPixel + pt::kTaskCounterBytes - 1) / pt::kTaskCounterBytes * pt::kTaskCounterBytes;
+        a.task_counters = (uint32_t*)(base + off);
+        off += pt::kTaskCounterBytes;
+        a.partials = (float4*)(base + off);
     } else {
         if (max_blocks > 1) IR_TRY(ensure(ctx, ctx->d_partials, (size_t)max_blocks * n * sizeof(float4)));
+        IR_TRY(ensure(ctx, ctx->d_prim, n * pt::kPrimBytesPerPixel));
+        IR_TRY(ensure(ctx, ctx->d_task_pixels, n * pt::kTaskBytesPerPixel));
+        IR_TRY(ensure(ctx, ctx->d_task_counters, pt::kTaskCounterBytes));
         a.partials = (float4*)ctx->d_partials.p;
+        a.prim = (float4*)ctx->d_prim.p;
+        a.task_pixels = (uint32_t*)ctx->d_task_pixels.p;
+        a.task_counters = (uint32_t*)ctx->d_task_counters.p;
     }
     IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     uint32_t done = 0;

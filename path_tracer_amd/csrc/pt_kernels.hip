@@ -39,22 +39,182 @@ __device__ __forceinline__ float4 sphere_at(const Args& a, const float4* s_sph, 
     }
 }
 
-// SKYMIS: sky importance sampling (IR_SKY_SAMPLING_MIS, pt_device.h): one more direction per traced bounce, drawn from
-// the sky's distribution and traced as a shadow ray; both strategies weighted with the balance heuristic.
-template <int ACCEL, bool STATS, bool SKYMIS>
-__global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
+// ----------------------------------------------------------------------------------------------------
+// Schedule.  A render launch is three kernels:
+//   primary_kernel : one lane per owned pixel.  Ray generation and the first closest hit have no random input
+//                    (pinhole_camera.rs:81-84: no pixel jitter), so they are evaluated once per pixel and launch.  A pixel
+//                    whose primary ray escapes is finished right here: every sample is the same sky value, its block
+//                    sums are formed by the same sequential adds and written out.  A pixel that hits something gets a
+//                    32-byte record (hit point, sphere, normal) and an entry in the list of path pixels;
+//   paths_kernel / paths_lbvh_kernel : persistent waves.  A TASK is one sample block of one path pixel (the reference's
+//                    TileAccumulator for that pixel, tile_buffer.rs:24-28: summed from zero in sample order).  A lane
+//                    takes a task, runs its samples in order with path regeneration (when a path ends, the lane adds it
+//                    to the block sum and restarts at the pixel's primary hit with the next sample index), writes the
+//                    block sum and takes the next task — lanes never wait for the slowest pixel of their wave or of
+//                    their workgroup, and a frame of any size fills the chip.  Waves draw tasks in chunks of 64 from one
+//                    global counter (one atomic per 64 tasks) and hand them to their lanes by ballot + mbcnt;
+//   merge_kernel   : block sums into the accumulator, in block order (full_buffer.rs:107-125).
+// Which lane runs a task never enters the arithmetic: results equal the one-lane-per-pixel formulation bit for bit.
+// ----------------------------------------------------------------------------------------------------
+constexpr uint32_t kTaskChunk = 64;
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {  // set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Wave-uniform task dispenser.  `want`: this lane asks for a task.  Returns true and the task id when it got one; false
+// when the queue is exhausted (or the lane did not ask).  Every lane of the wave must call it together.
+struct TaskPool {
+    uint32_t next = 0, end = 0;  // wave-uniform: unclaimed ids [next, end) of the wave's current chunk
+};
+__device__ __forceinline__ bool take_task(TaskPool& pool, uint32_t* cursor, uint32_t n_tasks, bool want, uint32_t& task) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+    if (m == 0ull) return false;
+    const uint32_t n = (uint32_t)__builtin_popcountll(m), avail = pool.end - pool.next;
+    uint32_t fresh = 0;
+    if (n > avail) {  // wave-uniform: one more chunk covers the request (n <= 64 = kTaskChunk)
+        const int leader = __builtin_ctzll(m);
+        uint32_t v = 0;
+        if ((int)(threadIdx.x & 63u) == leader) v = atomicAdd(cursor, kTaskChunk);
+        fresh = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
+    }
+    const uint32_t rank = lane_rank(m);
+    task = rank < avail ? pool.next + rank : fresh + (rank - avail);
+    if (n > avail) {
+        pool.next = fresh + (n - avail);
+        pool.end = fresh + kTaskChunk;
+    } else {
+        pool.next += n;
+    }
+    return want && task < n_tasks;
+}
+
+// Primary pass.  grid = owned tiles x 16 workgroups of 16x16 pixels.
+template <int ACCEL, bool STATS>
+__global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
-
-    // grid = sample blocks (slowest) x owned tiles x 16 workgroups per tile
-    const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
     uint32_t x, y;
-    if (!lane_pixel(wg, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
+    if (!lane_pixel(blockIdx.x, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
     const uint32_t pixel = y * a.w + x;
+    Ray r0;
+    if (a.rays) {
+        const float* p = a.rays + 6 * (size_t)pixel;
+        r0.o = mk3(p[0], p[1], p[2]);
+        r0.d = mk3(p[3], p[4], p[5]);
+    } else {
+        r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
+    }
+    WorkCounters wc0 = {0, 0, 0};
+    HitRec h0;
+    h0.t = kF32Max;
+    h0.idx = -1;
+    // integrator.rs:47: with bounces == 0 the loop never runs and every sample is (0, 0, 0, 1)
+    if (a.bounces != 0) h0 = trace_any<ACCEL, STATS>(a, s_sph, r0.o, r0.d, wc0);
+    const bool hit = h0.idx >= 0;
+    const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(hit);
+    if (hit) {
+        f3 pos0, nrm0;
+        hit_geometry(sphere_at<ACCEL>(a, s_sph, h0.idx), r0.o, r0.d, h0.t, pos0, nrm0);
+        a.prim[2 * (size_t)pixel] = make_float4(pos0.x, pos0.y, pos0.z, __builtin_bit_cast(float, h0.idx));
+        a.prim[2 * (size_t)pixel + 1] = make_float4(nrm0.x, nrm0.y, nrm0.z, __builtin_bit_cast(float, wc0.disc));
+        const int leader = __builtin_ctzll(hit_mask);
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&a.task_counters[0], (uint32_t)__builtin_popcountll(hit_mask));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        a.task_pixels[base + lane_rank(hit_mask)] = pixel;
+    } else {
+        // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89); its block sums are
+        // the same sequential adds the path lanes would make: one full block, and the shorter last one on the way
+        f3 light = mk3(0.0f, 0.0f, 0.0f);
+        if (a.bounces != 0) light = light + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
+        const uint32_t n_full = a.spp / a.sample_block, rem = a.spp % a.sample_block;
+        const uint32_t len = n_full ? a.sample_block : rem;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), last = acc;
+        for (uint32_t s = 0; s < len; ++s) {
+            acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
+            if (s + 1 == rem) last = acc;
+        }
+        if (a.partials) {
+            const size_t npix = (size_t)a.w * a.h;
+            for (uint32_t blk = 0; blk < a.n_blocks; ++blk) a.partials[(size_t)blk * npix + pixel] = blk < n_full ? acc : last;
+        } else {  // a single block: merged right here
+            float4 t = a.sum[pixel];
+            t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+            a.sum[pixel] = t;
+            a.counts[pixel] += a.spp;
+        }
+        if (STATS) {  // algorithmic counts, as the reference would execute them: the primary ray per sample
+            atomicAdd(&a.stats[0], (unsigned long long)a.spp);
+            if (a.bounces != 0) {
+                atomicAdd(&a.stats[1], (unsigned long long)a.spp);
+                atomicAdd(&a.stats[2], (unsigned long long)a.spp * a.n_spheres);
+                atomicAdd(&a.stats[3], (unsigned long long)wc0.disc * a.spp);
+            }
+        }
+    }
+    if (STATS) {  // executed acceleration-structure work of the shared primary trace: once per launch
+        atomicAdd(&a.stats[5], (unsigned long long)wc0.nodes);
+        atomicAdd(&a.stats[6], (unsigned long long)wc0.leaves);
+    }
+}
 
-    // per-lane work statistics (STATS only): traces, discriminant >= 0 tests, hits
-    uint32_t n_traces = 0, n_disc = 0, n_hits = 0;
-    WorkCounters wc0 = {0, 0, 0}, wc = {0, 0, 0};
+// State of the task a lane works on: a few registers; what follows from (pixel, block) is recomputed where it is needed.
+struct TaskState {
+    uint32_t pixel, blk, s;  // s = samples of the block done so far
+    float4 acc;              // the block sum
+};
+struct PrimaryHit {  // the pixel's record from primary_kernel
+    f3 pos, nrm;
+    int idx;
+    uint32_t disc;  // tests with discriminant >= 0 of the primary trace (statistics)
+};
+__device__ __forceinline__ uint32_t task_spp(const RenderArgs& a, uint32_t blk) {
+    const uint32_t first = blk * a.sample_block;
+    return (a.spp - first < a.sample_block) ? a.spp - first : a.sample_block;
+}
+__device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t pixel) {
+    const float4 r0 = a.prim[2 * (size_t)pixel], r1 = a.prim[2 * (size_t)pixel + 1];
+    PrimaryHit h;
+    h.pos = mk3(r0.x, r0.y, r0.z);
+    h.idx = __builtin_bit_cast(int, r0.w);
+    h.nrm = mk3(r1.x, r1.y, r1.z);
+    h.disc = f32_bits(r1.w);
+    return h;
+}
+__device__ __forceinline__ void begin_task(const RenderArgs& a, uint32_t task, TaskState& t) {
+    const uint32_t h = task / a.n_blocks;
+    t.blk = task - h * a.n_blocks;
+    t.pixel = a.task_pixels[h];
+    t.s = 0;
+    t.acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+// The block sum leaves the lane: the reference's merge of one TileAccumulator pixel (full_buffer.rs:107-125), deferred to
+// merge_kernel when the launch has several blocks.
+__device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t) {
+    if (a.partials) {
+        a.partials[(size_t)t.blk * ((size_t)a.w * a.h) + t.pixel] = t.acc;
+    } else {
+        float4 v = a.sum[t.pixel];
+        v.x += t.acc.x; v.y += t.acc.y; v.z += t.acc.z; v.w += t.acc.w;
+        a.sum[t.pixel] = v;
+        a.counts[t.pixel] += task_spp(a, t.blk);
+    }
+}
+
+// SKYMIS: sky importance sampling (IR_SKY_SAMPLING_MIS, pt_device.h): one more direction per traced bounce, drawn from
+// the sky's distribution and traced as a shadow ray; both strategies weighted with the balance heuristic.
+template <bool STATS, bool SKYMIS>
+__global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
+    extern __shared__ float4 s_sph[];
+    stage_spheres(s_sph, a.spheres, a.n_spheres);
+    const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
+    uint32_t* const cursor = a.task_counters + 1;
+    TaskPool pool;
+
+    // per-lane work statistics (STATS only): samples, traces, discriminant >= 0 tests, hits
+    uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
+    WorkCounters wc = {0, 0, 0};
     // lane-activity profile (STATS only): for the loop top and its three lane-dependent sections, how many times a wave
     // ran the section (counted on its first active lane) and how many lanes were active in it
     uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -66,203 +226,179 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
         }
     };
 
-    // ---- primary ray + primary closest hit (shared by all samples of the pixel)
-    Ray r0;
-    if (a.rays) {
-        const float* p = a.rays + 6 * (size_t)pixel;
-        r0.o = mk3(p[0], p[1], p[2]);
-        r0.d = mk3(p[3], p[4], p[5]);
-    } else {
-        r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
-    }
-    // this workgroup's sample block: like one reference render() call it sums its samples from zero in sample order
-    // (TileAccumulator, tile_buffer.rs:24-28); the block sums are then merged into the accumulator in block order
-    // (Accumulator::merge_tile, full_buffer.rs:107-125), by merge_kernel or, for a single block, right here
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const uint32_t first = blk * a.sample_block;
-    const uint32_t spp = (a.spp - first < a.sample_block) ? a.spp - first : a.sample_block;
-    const uint32_t sample_base = a.sample_base + first;
     const uint32_t B = a.bounces, R = a.rr_start;
     const bool fast = a.fast_materials != 0;
+    const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
+    TaskState t;
+    t.pixel = t.blk = t.s = 0;
+    t.acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    PrimaryHit p0;  // of the task's pixel; three spheres leave the registers for it
+    p0.pos = p0.nrm = mk3(0.0f, 0.0f, 0.0f);
+    p0.idx = 0;
+    p0.disc = 0;
+    uint32_t t_spp = 0, t_key = 0, t_base = 0;  // samples of the block, pixel key, first sample index of the block
+    bool have = false, finished = false;
+    // path state
+    uint32_t b = 0, skey = 0;
+    f3 pos = p0.pos, nrm = p0.nrm;
+    int idx = 0;
+    f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
 
-    if (B == 0) {
-        // integrator.rs:47: the bounce loop never runs, every sample is (0,0,0,1)
-        for (uint32_t s = 0; s < spp; ++s) {
-            acc.x += 0.0f; acc.y += 0.0f; acc.z += 0.0f; acc.w += 1.0f;
+    for (;;) {
+        // ---- lanes without a task take the next one
+        uint32_t task = 0;
+        const bool want = !have && !finished;
+        if (take_task(pool, cursor, n_tasks, want, task)) {
+            begin_task(a, task, t);
+            p0 = load_primary(a, t.pixel);
+            t_spp = task_spp(a, t.blk);
+            t_key = pixel_key(a.seed_lo, t.pixel);
+            t_base = a.sample_base + t.blk * a.sample_block;
+            have = true;
+            b = 0;
+            skey = sample_key(a.seed_hi, t_key, t_base);
+            pos = p0.pos; nrm = p0.nrm; idx = p0.idx;
+            contrib = mk3(1.0f, 1.0f, 1.0f);
+            light = mk3(0.0f, 0.0f, 0.0f);
+            if (STATS) { n_traces++; n_disc += p0.disc; n_hits++; }
+        } else if (want) {
+            finished = true;
         }
-    } else {
-        const HitRec h0 = trace_any<ACCEL, STATS>(a, s_sph, r0.o, r0.d, wc0);
-        const uint32_t disc0 = wc0.disc;
-        if (h0.idx < 0) {
-            // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89)
-            f3 light = mk3(0.0f, 0.0f, 0.0f) + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
-            for (uint32_t s = 0; s < spp; ++s) {
-                acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
-            }
-            if (STATS) {
-                n_traces = spp;
-                n_disc = disc0 * spp;
-            }
-        } else {
-            f3 pos0, nrm0;
-            {
-                const float4 sp = sphere_at<ACCEL>(a, s_sph, h0.idx);
-                hit_geometry(sp, r0.o, r0.d, h0.t, pos0, nrm0);
-            }
-            const int idx0 = h0.idx;
-            const uint32_t pkey = pixel_key(a.seed_lo, pixel);
-
-            uint32_t s = 0, b = 0;
-            uint32_t skey = sample_key(a.seed_hi, pkey, sample_base);
-            f3 pos = pos0, nrm = nrm0;
-            int idx = idx0;
-            f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
-            if (STATS) { n_traces = 1; n_disc = disc0; n_hits = 1; }
-            const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
-
-            while (s < spp) {
-                profile(0);
-                // ---- shade the hit of bounce b (integrator.rs:50-81)
-                const float4 m_brdf = a.shade[2 * idx];
-                const float4 m_emit = a.shade[2 * idx + 1];
-                light = light + mk3(m_emit.x, m_emit.y, m_emit.z) * contrib;
-                const float r1 = draw(skey, 3 * b);
-                const float r2 = draw(skey, 3 * b + 1);
-                const f3 wi = sample_hemisphere(nrm, r1, r2);
-                const float cos_theta = __builtin_fmaxf(dot(wi, nrm), 0.0f);
-                contrib = contrib * scatter_weight(mk3(m_brdf.x, m_brdf.y, m_brdf.z), cos_theta, fast);
-                bool done = false;
-                if (b >= R) {
-                    profile(1);
-                    const float p = __builtin_fmaxf(contrib.x, __builtin_fmaxf(contrib.y, contrib.z));
-                    if (draw(skey, 3 * b + 2) > p) {
-                        done = true;
-                    } else {
-                        contrib = roulette_divide(contrib, p, fast);
-                    }
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;  // every lane ran out of tasks
+        if (have) {
+            profile(0);
+            // ---- shade the hit of bounce b (integrator.rs:50-81)
+            const float4 m_brdf = a.shade[2 * idx];
+            const float4 m_emit = a.shade[2 * idx + 1];
+            light = light + mk3(m_emit.x, m_emit.y, m_emit.z) * contrib;
+            const float r1 = draw(skey, 3 * b);
+            const float r2 = draw(skey, 3 * b + 1);
+            const f3 wi = sample_hemisphere(nrm, r1, r2);
+            const float cos_theta = __builtin_fmaxf(dot(wi, nrm), 0.0f);
+            contrib = contrib * scatter_weight(mk3(m_brdf.x, m_brdf.y, m_brdf.z), cos_theta, fast);
+            bool done = false;
+            if (b >= R) {
+                profile(1);
+                const float p = __builtin_fmaxf(contrib.x, __builtin_fmaxf(contrib.y, contrib.z));
+                if (draw(skey, 3 * b + 2) > p) {
+                    done = true;
+                } else {
+                    contrib = roulette_divide(contrib, p, fast);
                 }
-                if (!done) {
-                    const f3 o = pos + nrm * kEps;
-                    const f3 d = wi;
-                    ++b;
-                    if (b < B) {
-                        float ray_density = 0.0f;
-                        if constexpr (SKYMIS) {
-                            ray_density = bsdf_density_r(sqrt_cr(r2));
-                            uint32_t ix, iy;
-                            f3 ws;
-                            float sin_polar;
-                            sky_sample(sky_tables, a.sky_w, a.sky_h, draw(skey, kSkyDrawBase + 2 * (b - 1)),
-                                       draw(skey, kSkyDrawBase + 2 * (b - 1) + 1), ix, iy, ws, sin_polar);
-                            const float c = dot(ws, nrm);
-                            if (c > 0.0f && sin_polar > 0.0f) {
-                                const size_t texel = (size_t)iy * a.sky_w + ix;
-                                const float pe = sky_density(sky_tables, texel, sin_polar);
-                                const float pa = bsdf_density_dir(c);
-                                const float wgt = pa / (pe + pa);
-                                const uint32_t before = wc.disc;
-                                const HitRec hs = trace_any<ACCEL, STATS>(a, s_sph, o, ws, wc);
-                                if (STATS) { n_traces++; n_disc += wc.disc - before; }
-                                if (hs.idx < 0) {
-                                    f3 sk;
-                                    if (a.sky_filter == 1) {
-                                        sk = sky_bilinear(a.skybox, a.sky_w, a.sky_h, ws);
-                                    } else {
-                                        const float4 t = a.skybox[texel];
-                                        sk = mk3(t.x, t.y, t.z);
-                                    }
-                                    light = light + (sk * contrib) * wgt;
+            }
+            if (!done) {
+                const f3 o = pos + nrm * kEps;
+                const f3 d = wi;
+                ++b;
+                if (b < B) {
+                    float ray_density = 0.0f;
+                    if constexpr (SKYMIS) {
+                        ray_density = bsdf_density_r(sqrt_cr(r2));
+                        uint32_t ix, iy;
+                        f3 ws;
+                        float sin_polar;
+                        sky_sample(sky_tables, a.sky_w, a.sky_h, draw(skey, kSkyDrawBase + 2 * (b - 1)),
+                                   draw(skey, kSkyDrawBase + 2 * (b - 1) + 1), ix, iy, ws, sin_polar);
+                        const float c = dot(ws, nrm);
+                        if (c > 0.0f && sin_polar > 0.0f) {
+                            const size_t texel = (size_t)iy * a.sky_w + ix;
+                            const float pe = sky_density(sky_tables, texel, sin_polar);
+                            const float pa = bsdf_density_dir(c);
+                            const float wgt = pa / (pe + pa);
+                            const uint32_t before = wc.disc;
+                            const HitRec hs = trace_linear<STATS>(s_sph, a.n_spheres, o, ws, wc.disc);
+                            if (STATS) { n_traces++; n_disc += wc.disc - before; }
+                            if (hs.idx < 0) {
+                                f3 sk;
+                                if (a.sky_filter == 1) {
+                                    sk = sky_bilinear(a.skybox, a.sky_w, a.sky_h, ws);
+                                } else {
+                                    const float4 tx = a.skybox[texel];
+                                    sk = mk3(tx.x, tx.y, tx.z);
                                 }
+                                light = light + (sk * contrib) * wgt;
                             }
                         }
-                        const uint32_t before = wc.disc;
-                        const HitRec h = trace_any<ACCEL, STATS>(a, s_sph, o, d, wc);
-                        if (STATS) { n_traces++; n_disc += wc.disc - before; }
-                        if (h.idx >= 0) {
-                            profile(2);
-                            if (STATS) n_hits++;
-                            const float4 sp = sphere_at<ACCEL>(a, s_sph, h.idx);
-                            hit_geometry(sp, o, d, h.t, pos, nrm);
-                            idx = h.idx;
-                        } else {
-                            profile(3);
-                            if constexpr (SKYMIS) {
-                                size_t texel;
-                                float sin_polar;
-                                const f3 sk = sky_lookup_mis(a.skybox, a.sky_w, a.sky_h, a.sky_filter, d, texel, sin_polar);
-                                const float pe = sky_density(sky_tables, texel, sin_polar);
-                                light = light + (sk * contrib) * (ray_density / (ray_density + pe));
-                            } else {
-                                light = light + sky_eval(a, d) * contrib;
-                            }
-                            done = true;
-                        }
-                    } else {
-                        done = true;  // bounce budget exhausted: no sky term (integrator.rs:47,92)
                     }
+                    const uint32_t before = wc.disc;
+                    const HitRec h = trace_linear<STATS>(s_sph, a.n_spheres, o, d, wc.disc);
+                    if (STATS) { n_traces++; n_disc += wc.disc - before; }
+                    if (h.idx >= 0) {
+                        profile(2);
+                        if (STATS) n_hits++;
+                        hit_geometry(s_sph[h.idx], o, d, h.t, pos, nrm);
+                        idx = h.idx;
+                    } else {
+                        profile(3);
+                        if constexpr (SKYMIS) {
+                            size_t texel;
+                            float sin_polar;
+                            const f3 sk = sky_lookup_mis(a.skybox, a.sky_w, a.sky_h, a.sky_filter, d, texel, sin_polar);
+                            const float pe = sky_density(sky_tables, texel, sin_polar);
+                            light = light + (sk * contrib) * (ray_density / (ray_density + pe));
+                        } else {
+                            light = light + sky_eval(a, d) * contrib;
+                        }
+                        done = true;
+                    }
+                } else {
+                    done = true;  // bounce budget exhausted: no sky term (integrator.rs:47,92)
                 }
-                if (done) {
-                    acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
-                    ++s;
+            }
+            if (done) {
+                t.acc.x += light.x; t.acc.y += light.y; t.acc.z += light.z; t.acc.w += 1.0f;
+                ++t.s;
+                if (t.s == t_spp) {
+                    end_task(a, t);
+                    if (STATS) n_samples += t_spp;
+                    have = false;
+                } else {  // regenerate at the primary hit with the next sample index
                     b = 0;
-                    pos = pos0; nrm = nrm0; idx = idx0;
+                    pos = p0.pos; nrm = p0.nrm; idx = p0.idx;
                     contrib = mk3(1.0f, 1.0f, 1.0f);
                     light = mk3(0.0f, 0.0f, 0.0f);
-                    skey = sample_key(a.seed_hi, pkey, sample_base + s);
-                    if (STATS && s < spp) { n_traces++; n_disc += disc0; n_hits++; }
+                    skey = sample_key(a.seed_hi, t_key, t_base + t.s);
+                    if (STATS) { n_traces++; n_disc += p0.disc; n_hits++; }
                 }
             }
         }
-    }
-    if (a.partials) {
-        a.partials[(size_t)blk * ((size_t)a.w * a.h) + pixel] = acc;
-    } else {
-        float4 t = a.sum[pixel];
-        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
-        a.sum[pixel] = t;
-        a.counts[pixel] += spp;
     }
 
     if (STATS) {
         // algorithmic counts, as the reference would execute them (primary ray per sample)
-        atomicAdd(&a.stats[0], (unsigned long long)spp);
+        atomicAdd(&a.stats[0], (unsigned long long)n_samples);
         atomicAdd(&a.stats[1], (unsigned long long)n_traces);
         atomicAdd(&a.stats[2], (unsigned long long)n_traces * a.n_spheres);
         atomicAdd(&a.stats[3], (unsigned long long)n_disc);
         atomicAdd(&a.stats[4], (unsigned long long)n_hits);
-        // executed acceleration-structure work (the shared primary trace is counted once per launch)
-        atomicAdd(&a.stats[5], (unsigned long long)wc.nodes + wc0.nodes);
-        atomicAdd(&a.stats[6], (unsigned long long)wc.leaves + wc0.leaves);
         for (int k = 0; k < 8; ++k)
             if (prof[k]) atomicAdd(&a.stats[7 + k], (unsigned long long)prof[k]);
     }
 }
 
 // ----------------------------------------------------------------------------------------------------
-// LBVH integrator: same samples, same sums as render_kernel, different schedule.  With a tree, the length of a
-// traversal varies wildly between the rays of one wave (measured on the 10k-sphere scene: 10 % of the lanes active
-// when every lane waits for the slowest ray of each bounce).  Here a lane is either TRAVERSING (it advances its own
-// ray by one node per step) or WAITING for the shading block (finish the previous ray: hit point or sky + sample
-// accumulation + regeneration; then emission, bounce sampling, roulette and the next ray).  The wave runs traversal
-// steps for whoever is traversing and runs the shading block only once enough lanes wait for it (or nobody is left
-// traversing), so short rays do not sit out long ones: they go on to their next ray.  Every lane still runs its own
-// pixel's samples in order, so per-pixel sums are unchanged.
+// LBVH integrator: same tasks, same sums.  With a tree, the length of a traversal varies wildly between the rays of one
+// wave (measured on the 10k-sphere scene: 10 % of the lanes active when every lane waits for the slowest ray of each
+// bounce).  Here a lane is either TRAVERSING (it advances its own ray by one node per step) or WAITING for the shading
+// block (finish the previous ray: hit point or sky + sample accumulation + regeneration or the next task; then emission,
+// bounce sampling, roulette and the next ray).  The wave runs traversal steps for whoever is traversing and runs the
+// shading block only once enough lanes wait for it (or nobody is left traversing), so short rays do not sit out long
+// ones: they go on to their next ray.
 // ----------------------------------------------------------------------------------------------------
 constexpr uint32_t kShadeBatch = 32;   // run the shading block when this many lanes wait for it
 constexpr uint32_t kStepsPerRound = 8; // traversal steps between two looks at the wave's state
 
-// SKYMIS (sky importance sampling, see render_kernel): the shadow ray is one more traversal of the lane's state machine,
+// SKYMIS (sky importance sampling, see paths_kernel): the shadow ray is one more traversal of the lane's state machine,
 // run before the bounce ray, which waits in registers (direction, density, the strategy's weighted sky term).
 template <bool STATS, bool SKYMIS>
-__global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const RenderArgs a) {
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
-    const uint32_t wg = blockIdx.x % a.wgs_per_layer, blk = blockIdx.x / a.wgs_per_layer;
-    uint32_t x, y;
-    if (!lane_pixel(wg, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
-    const uint32_t pixel = y * a.w + x;
-    uint32_t n_traces = 0, n_disc = 0, n_hits = 0;
-    WorkCounters wc0 = {0, 0, 0}, wc = {0, 0, 0};
+    const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;
+    uint32_t* const cursor = a.task_counters + 1;
+    TaskPool pool;
+    uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
+    WorkCounters wc = {0, 0, 0};
     // lane-activity profile (STATS only; ir_get_lane_profile): rounds of the wave loop (lanes with work left), shading
     // block, inner-node steps, leaf steps — wave executions (counted on the first active lane) and active lanes
     uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -273,48 +409,34 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
             prof[2 * section + 1] += 1u;
         }
     };
-
-    Ray r0;
-    if (a.rays) {
-        const float* p = a.rays + 6 * (size_t)pixel;
-        r0.o = mk3(p[0], p[1], p[2]);
-        r0.d = mk3(p[3], p[4], p[5]);
-    } else {
-        r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
-    }
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const uint32_t first = blk * a.sample_block;
-    const uint32_t spp = (a.spp - first < a.sample_block) ? a.spp - first : a.sample_block;
-    const uint32_t sample_base = a.sample_base + first;
     const uint32_t B = a.bounces, R = a.rr_start;
     const bool fast = a.fast_materials != 0;
+    const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
 
-    uint32_t s = 0;  // samples finished by this lane; the lane has work while s < spp
-    f3 pos0 = mk3(0, 0, 0), nrm0 = mk3(0, 0, 0);
-    int idx0 = -1;
-    uint32_t disc0 = 0;
-    if (B == 0) {
-        for (; s < spp; ++s) { acc.x += 0.0f; acc.y += 0.0f; acc.z += 0.0f; acc.w += 1.0f; }
-    } else {
-        const HitRec h0 = trace_lbvh<STATS>(a.bvh, stack, 256u, r0.o, r0.d, wc0.disc, wc0.nodes, wc0.leaves);
-        disc0 = wc0.disc;
-        if (h0.idx < 0) {
-            f3 light = mk3(0.0f, 0.0f, 0.0f) + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
-            for (; s < spp; ++s) { acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f; }
-            if (STATS) { n_traces = spp; n_disc = disc0 * spp; }
-        } else {
-            hit_geometry(a.spheres[h0.idx], r0.o, r0.d, h0.t, pos0, nrm0);
-            idx0 = h0.idx;
-            if (STATS) { n_traces = 1; n_disc = disc0; n_hits = 1; }
-        }
-    }
-    const uint32_t pkey = pixel_key(a.seed_lo, pixel);
-    uint32_t b = 0;
-    uint32_t skey = sample_key(a.seed_hi, pkey, sample_base);
-    f3 pos = pos0, nrm = nrm0;
-    int idx = idx0;
+    // The task's state (pixel, block, samples done, block sum) is touched once per sample: it lives in LDS behind the
+    // traversal stacks, not in 7 registers (80 VGPRs = 6 waves per SIMD is what this kernel lives on).  For the same
+    // reason the shading point is not kept: the next ray's origin, pos + nrm * EPSILON (integrator.rs:80), goes straight
+    // into the cursor, and the pixel's primary-hit record is read again for every sample (an L1/L2 hit).
+    uint32_t* const s_task = reinterpret_cast<uint32_t*>(s_dyn) + (size_t)a.bvh.stack_depth * 256 + threadIdx.x;
+    auto task_word = [&](int k) -> uint32_t& { return s_task[k * 256]; };  // 0 pixel, 1 block, 2 samples done, 3..6 sum
+    bool have = false, finished = false;
+    uint32_t b = 0, skey = 0;
+    f3 nrm = mk3(0.0f, 0.0f, 0.0f);
+    int idx = 0;
     f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
     LbvhCursor cur;
+    auto restart = [&]() {  // a sample starts at the pixel's primary hit
+        const uint32_t pixel = task_word(0), blk = task_word(1), done = task_word(2);
+        const PrimaryHit p0 = load_primary(a, pixel);
+        b = 0;
+        cur.o = p0.pos + p0.nrm * kEps;
+        nrm = p0.nrm;
+        idx = p0.idx;
+        contrib = mk3(1.0f, 1.0f, 1.0f);
+        light = mk3(0.0f, 0.0f, 0.0f);
+        skey = sample_key(a.seed_hi, pixel_key(a.seed_lo, pixel), a.sample_base + blk * a.sample_block + done);
+        if (STATS) { n_traces++; n_disc += p0.disc; n_hits++; }
+    };
     cursor_begin(cur, mk3(0, 0, 0), mk3(0, 0, 1));
     cur.cur = kCursorDone;
     bool traversing = false;  // cur holds an unfinished traversal
@@ -323,16 +445,29 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
     bool shadow = false;
     f3 wi_next = mk3(0, 0, 0), sky_term = mk3(0, 0, 0);
     float ray_density = 0.0f;
-    const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
 
     for (;;) {
-        const bool waiting = !traversing && s < spp;
+        // lanes that are not traversing want the shading block: to take a task, or to go on with the one they have
+        const bool waiting = !traversing && !finished;
         const uint32_t n_wait = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(waiting));
         const uint32_t n_trav = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(traversing));
         if (n_wait == 0 && n_trav == 0) break;
         if (waiting || traversing) profile(0);
         if (n_wait >= kShadeBatch || n_trav == 0) {
-            if (waiting) {
+            uint32_t task = 0;
+            const bool want = waiting && !have;
+            if (take_task(pool, cursor, n_tasks, want, task)) {
+                const uint32_t h = task / a.n_blocks;
+                task_word(0) = a.task_pixels[h];
+                task_word(1) = task - h * a.n_blocks;
+                task_word(2) = 0u;
+                task_word(3) = task_word(4) = task_word(5) = task_word(6) = 0u;  // the block sum starts at +0
+                have = true;
+                restart();
+            } else if (want) {
+                finished = true;
+            }
+            if (waiting && have) {
                 profile(1);
                 if (landed) {  // consume the finished traversal (integrator.rs:50-51, 82-90)
                     landed = false;
@@ -340,12 +475,14 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
                     if (SKYMIS && shadow) {
                         if (cur.idx < 0) light = light + sky_term;
                         shadow = false;
-                        cursor_begin(cur, pos + nrm * kEps, wi_next);
+                        cursor_begin(cur, cur.o, wi_next);  // the bounce ray leaves the same point as the shadow ray
                         traversing = true;
                     } else if (cur.idx >= 0) {
                         if (STATS) n_hits++;
+                        f3 pos;
                         hit_geometry(a.spheres[cur.idx], cur.o, cur.d, cur.best, pos, nrm);
                         idx = cur.idx;
+                        cur.o = pos + nrm * kEps;
                     } else {
                         if constexpr (SKYMIS) {
                             size_t texel;
@@ -360,16 +497,26 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
                     }
                 }
                 if (!SKYMIS || !traversing) for (;;) {
-                    if (idx < 0) {  // finish the sample, regenerate at the primary hit
+                    if (idx < 0) {  // finish the sample; regenerate at the primary hit, or hand the block sum in
+                        float4 acc = make_float4(__builtin_bit_cast(float, task_word(3)), __builtin_bit_cast(float, task_word(4)),
+                                                 __builtin_bit_cast(float, task_word(5)), __builtin_bit_cast(float, task_word(6)));
                         acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
-                        ++s;
-                        if (s >= spp) break;
-                        b = 0;
-                        pos = pos0; nrm = nrm0; idx = idx0;
-                        contrib = mk3(1.0f, 1.0f, 1.0f);
-                        light = mk3(0.0f, 0.0f, 0.0f);
-                        skey = sample_key(a.seed_hi, pkey, sample_base + s);
-                        if (STATS) { n_traces++; n_disc += disc0; n_hits++; }
+                        const uint32_t done_now = task_word(2) + 1u, blk = task_word(1);
+                        if (done_now >= task_spp(a, blk)) {
+                            TaskState t;
+                            t.pixel = task_word(0);
+                            t.blk = blk;
+                            t.s = done_now;
+                            t.acc = acc;
+                            end_task(a, t);
+                            if (STATS) n_samples += done_now;
+                            have = false;  // the next shading block brings the next task
+                            break;
+                        }
+                        task_word(2) = done_now;
+                        task_word(3) = f32_bits(acc.x); task_word(4) = f32_bits(acc.y);
+                        task_word(5) = f32_bits(acc.z); task_word(6) = f32_bits(acc.w);
+                        restart();
                     }
                     // shade the hit of bounce b (integrator.rs:50-81)
                     const float4 m_brdf = a.shade[2 * idx];
@@ -408,18 +555,18 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
                                     if (a.sky_filter == 1) {
                                         sk = sky_bilinear(a.skybox, a.sky_w, a.sky_h, ws);
                                     } else {
-                                        const float4 t = a.skybox[texel];
-                                        sk = mk3(t.x, t.y, t.z);
+                                        const float4 tx = a.skybox[texel];
+                                        sk = mk3(tx.x, tx.y, tx.z);
                                     }
                                     sky_term = (sk * contrib) * (pa / (pe + pa));
                                     wi_next = wi;
                                     shadow = true;
-                                    cursor_begin(cur, pos + nrm * kEps, ws);
+                                    cursor_begin(cur, cur.o, ws);
                                     traversing = true;
                                     break;
                                 }
                             }
-                            cursor_begin(cur, pos + nrm * kEps, wi);
+                            cursor_begin(cur, cur.o, wi);
                             traversing = true;
                             break;
                         }
@@ -445,22 +592,14 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void render_lbvh_kernel(const 
     }
     if (STATS) n_disc += wc.disc;
 
-    if (a.partials) {
-        a.partials[(size_t)blk * ((size_t)a.w * a.h) + pixel] = acc;
-    } else {
-        float4 t = a.sum[pixel];
-        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
-        a.sum[pixel] = t;
-        a.counts[pixel] += spp;
-    }
     if (STATS) {
-        atomicAdd(&a.stats[0], (unsigned long long)spp);
+        atomicAdd(&a.stats[0], (unsigned long long)n_samples);
         atomicAdd(&a.stats[1], (unsigned long long)n_traces);
         atomicAdd(&a.stats[2], (unsigned long long)n_traces * a.n_spheres);
         atomicAdd(&a.stats[3], (unsigned long long)n_disc);
         atomicAdd(&a.stats[4], (unsigned long long)n_hits);
-        atomicAdd(&a.stats[5], (unsigned long long)wc.nodes + wc0.nodes);
-        atomicAdd(&a.stats[6], (unsigned long long)wc.leaves + wc0.leaves);
+        atomicAdd(&a.stats[5], (unsigned long long)wc.nodes);
+        atomicAdd(&a.stats[6], (unsigned long long)wc.leaves);
         for (int k = 0; k < 8; ++k)
             if (prof[k]) atomicAdd(&a.stats[7 + k], (unsigned long long)prof[k]);
     }
@@ -536,17 +675,37 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
 hipError_t init_kernels() {
     hipError_t e;
     const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
-    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)render_kernel<kAccelLinear, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)primary_hits_kernel<kAccelLinear>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    return e;
+    const void* big_lds[] = {(const void*)paths_kernel<false, false>,          (const void*)paths_kernel<true, false>,
+                             (const void*)paths_kernel<false, true>,           (const void*)paths_kernel<true, true>,
+                             (const void*)primary_kernel<kAccelLinear, false>, (const void*)primary_kernel<kAccelLinear, true>,
+                             (const void*)primary_hits_kernel<kAccelLinear>};
+    for (const void* f : big_lds) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
+
+namespace {
+
+// Workgroups of a persistent launch: what the device can hold at once (CUs x resident workgroups per CU for this kernel
+// and LDS size), never more than the tasks can occupy.  A workgroup too many only queues and finds the task list empty.
+hipError_t persistent_grid(const void* kernel, size_t lds, uint64_t max_tasks, uint32_t* out) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds);
+    if (e != hipSuccess) return e;
+    if (cus < 1) cus = 1;
+    if (per_cu < 1) per_cu = 1;
+    uint64_t wgs = (uint64_t)cus * (uint64_t)per_cu;
+    const uint64_t useful = (max_tasks + 255) / 256;
+    if (wgs > useful) wgs = useful;
+    *out = (uint32_t)(wgs < 1 ? 1 : wgs);
+    return hipSuccess;
+}
+
+}  // namespace
 
 hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStream_t stream) {
     const uint32_t owned = owned_tiles(a_in.n_tiles, a_in.tile_rank, a_in.tile_world);
@@ -554,33 +713,38 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     RenderArgs a = a_in;
     a.wgs_per_layer = owned * kBlocksPerTile;
     a.n_blocks = (a.spp + a.sample_block - 1) / a.sample_block;
-    if (a.n_blocks == 1) a.partials = nullptr;  // single block: the kernel merges into the accumulator itself
-    const dim3 grid(a.wgs_per_layer * a.n_blocks), block(256);
+    if (a.n_blocks == 1) a.partials = nullptr;  // single block: the kernels merge into the accumulator themselves
+    const dim3 block(256);
+    hipError_t e = hipMemsetAsync(a.task_counters, 0, 2 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const bool skymis = a.sky_marginal != nullptr;
+    const uint64_t max_tasks = (uint64_t)a.wgs_per_layer * 256u * a.n_blocks;
+    const void* paths = nullptr;
+    size_t lds = 0;
     if (accel == kAccelLbvh) {
-        const size_t lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int);
-        const bool skymis = a.sky_marginal != nullptr;
-        if (stats) {
-            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<true, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((render_lbvh_kernel<true, false>), grid, block, lds, stream, a);
-        } else {
-            if (skymis) hipLaunchKernelGGL((render_lbvh_kernel<false, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((render_lbvh_kernel<false, false>), grid, block, lds, stream, a);
-        }
+        lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int);
+        if (stats) hipLaunchKernelGGL((primary_kernel<kAccelLbvh, true>), dim3(a.wgs_per_layer), block, lds, stream, a);
+        else hipLaunchKernelGGL((primary_kernel<kAccelLbvh, false>), dim3(a.wgs_per_layer), block, lds, stream, a);
+        lds += 7 * 256 * sizeof(uint32_t);  // paths_lbvh_kernel keeps each lane's task state behind the stacks
+        paths = stats ? (skymis ? (const void*)paths_lbvh_kernel<true, true> : (const void*)paths_lbvh_kernel<true, false>)
+                      : (skymis ? (const void*)paths_lbvh_kernel<false, true> : (const void*)paths_lbvh_kernel<false, false>);
     } else {
-        size_t lds = (size_t)a.n_spheres * sizeof(float4);
+        lds = (size_t)a.n_spheres * sizeof(float4);
         // occupancy experiments only (tools/): IR_DEBUG_LDS_PAD=<bytes> pads the workgroup's LDS allocation
         static const size_t pad = getenv("IR_DEBUG_LDS_PAD") ? (size_t)atol(getenv("IR_DEBUG_LDS_PAD")) : 0;
         if (lds + pad <= kMaxLdsSpheres * sizeof(float4)) lds += pad;
-        const bool skymis = a.sky_marginal != nullptr;
-        if (stats) {
-            if (skymis) hipLaunchKernelGGL((render_kernel<kAccelLinear, true, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((render_kernel<kAccelLinear, true, false>), grid, block, lds, stream, a);
-        } else {
-            if (skymis) hipLaunchKernelGGL((render_kernel<kAccelLinear, false, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((render_kernel<kAccelLinear, false, false>), grid, block, lds, stream, a);
-        }
+        if (stats) hipLaunchKernelGGL((primary_kernel<kAccelLinear, true>), dim3(a.wgs_per_layer), block, lds, stream, a);
+        else hipLaunchKernelGGL((primary_kernel<kAccelLinear, false>), dim3(a.wgs_per_layer), block, lds, stream, a);
+        paths = stats ? (skymis ? (const void*)paths_kernel<true, true> : (const void*)paths_kernel<true, false>)
+                      : (skymis ? (const void*)paths_kernel<false, true> : (const void*)paths_kernel<false, false>);
     }
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint32_t grid = 1;
+    e = persistent_grid(paths, lds, max_tasks, &grid);
+    if (e != hipSuccess) return e;
+    void* params[] = {(void*)&a};
+    e = hipLaunchKernel(paths, dim3(grid), block, params, lds, stream);
     if (e != hipSuccess) return e;
     if (a.n_blocks > 1) {
         hipLaunchKernelGGL(merge_kernel, dim3(a.wgs_per_layer), block, 0, stream, a);
