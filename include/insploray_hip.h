@@ -156,11 +156,11 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
  * sums are merged into the accumulator in block order.  Blocks are independent until the merge, which is what lets
  * one call fill the GPU.  On a zeroed accumulator a call with spp <= samples_per_block is bit-identical to spp
  * successive reference-style 1-sample calls.
- * IR_SAMPLE_BLOCK_AUTO (0): 128, halved (not below 8) until the launch has at least 8192 workgroups, i.e. the blocks
- * shrink for small frames and low sample counts so that the 256 CUs stay full (the reference's own headless case, 800x450
- * at 64 spp, is one block on 1407 workgroups otherwise).  A pure function of the workgroups per block — 16 per 64x64 tile
- * this rank owns — and spp; ir_get_sample_block returns what a render of that shape would use, so that a caller (or a
- * checker) can reproduce the order of the sums. */
+ * IR_SAMPLE_BLOCK_AUTO (0): 128, halved (not below 8) until the launch has at least 4096 x 256 (pixel, block) tasks: a
+ * small frame at a low sample count otherwise lasts as long as its longest block runs on one lane (the reference's own
+ * headless case, 800x450 at 64 spp: 16-sample blocks render it in half the time of one 64-sample block per pixel).  A pure
+ * function of the pixels this rank owns — 4096 per 64x64 tile — and spp; ir_get_sample_block returns what a render of
+ * that shape would use, so that a caller (or a checker) can reproduce the order of the sums. */
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);
 int ir_get_sample_block(const ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t* out_samples_per_block);
 

@@ -130,10 +130,12 @@ int selected_accel(const ir_context* ctx) {
 }
 
 // Samples per accumulation block of a render when ir_set_sample_block selected IR_SAMPLE_BLOCK_AUTO: 128, halved (not
-// below 8) until the launch has at least kAutoMinWorkgroups workgroups, so that small frames and low sample counts still
-// fill the 256 CUs several times over (C1, 800x450x64: 1407 workgroups with one block of 64).  A pure function of the
-// workgroups per sample block and spp, so that a caller (and the oracle in the tests) can reproduce the sum order.
-constexpr uint32_t kAutoMinWorkgroups = 8192;
+// below 8) until the launch has at least kAutoMinWorkgroups x 256 (pixel, block) tasks.  A small launch lasts as long as
+// its longest task runs on one lane (C1, 800x450x64: 0.81 ms of path kernel with one 64-sample task per pixel, 0.38 ms
+// with four tasks of 16); shorter tasks still cost a task switch each (8-sample tasks: slower again).  A pure function of
+// the workgroups-worth of pixels this rank owns and spp, so that a caller (and the oracle in the tests) can reproduce the
+// sum order.
+constexpr uint32_t kAutoMinWorkgroups = 4096;
 uint32_t auto_sample_block(uint32_t wgs_per_block, uint32_t spp) {
     uint32_t sb = 128;
     while (sb > 8 && (uint64_t)wgs_per_block * ((spp + sb - 1) / sb) < kAutoMinWorkgroups) sb /= 2;
@@ -741,7 +743,7 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         if (!base) return fail(ctx, IR_ESTATE, "%s: no static scratch on device %d", who, ctx->device);
         a.prim = (float4*)base;
         size_t off = n * pt::kPrimBytesPerPixel;
-        a.task_pixels = (uint32_t*)(base + off);
+        a.prim_disc = (uint32_t*)(base + off);
         off = (off + n * pt::kTaskBytesPerPixel + pt::kTaskCounterBytes - 1) / pt::kTaskCounterBytes * pt::kTaskCounterBytes;
         a.task_counters = (uint32_t*)(base + off);
         off += pt::kTaskCounterBytes;
@@ -753,7 +755,7 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         IR_TRY(ensure(ctx, ctx->d_task_counters, pt::kTaskCounterBytes));
         a.partials = (float4*)ctx->d_partials.p;
         a.prim = (float4*)ctx->d_prim.p;
-        a.task_pixels = (uint32_t*)ctx->d_task_pixels.p;
+        a.prim_disc = (uint32_t*)ctx->d_task_pixels.p;
         a.task_counters = (uint32_t*)ctx->d_task_counters.p;
     }
     IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

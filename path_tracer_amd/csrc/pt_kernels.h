@@ -50,9 +50,9 @@ struct RenderArgs {
     uint32_t* counts;  // samples per pixel
 
     // Launch scratch of the primary pass and the task dispenser (pt_kernels.hip "Schedule"):
-    float4* prim;             // per pixel whose primary ray hits: [2p] = (hit point, sphere index bits), [2p+1] = (normal, disc>=0 count bits)
-    uint32_t* task_pixels;    // those pixels, in the order the primary pass found them
-    uint32_t* task_counters;  // [0] = their number, [1] = next unclaimed task (task = list entry * n_blocks + block)
+    float4* prim;             // list of path pixels (primary ray hits): [2e] = (hit point, pixel bits), [2e+1] = (normal, sphere index bits)
+    uint32_t* prim_disc;      // per list entry: tests with discriminant >= 0 of the primary trace (statistics)
+    uint32_t* task_counters;  // [0] = list length, [1] = next unclaimed task (task = list entry * n_blocks + block)
 
     // tile partition: this launch renders tiles t = tile_rank + k * tile_world, k = 0 .. n_owned_tiles-1
     uint32_t tiles_x, n_tiles, tile_rank, tile_world;
@@ -136,7 +136,7 @@ hipError_t launch_wavefront(const WfArgs& a, int accel, uint32_t per_batch, uint
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 enum { kAccelLinear = 0, kAccelLbvh = 1 };
 constexpr uint32_t kNumStats = 15;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests, 8 x lane profile
-// scratch the launch needs besides `partials`: prim (32 B per pixel), task_pixels (4 B per pixel), task_counters (8 B)
+// scratch the launch needs besides `partials`: prim (32 B per pixel), prim_disc (4 B per pixel), task_counters (8 B)
 constexpr size_t kPrimBytesPerPixel = 32, kTaskBytesPerPixel = 4, kTaskCounterBytes = 256;
 hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream);
 hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream);

@@ -45,7 +45,7 @@ __device__ __forceinline__ float4 sphere_at(const Args& a, const float4* s_sph, 
 //                    (pinhole_camera.rs:81-84: no pixel jitter), so they are evaluated once per pixel and launch.  A pixel
 //                    whose primary ray escapes is finished right here: every sample is the same sky value, its block
 //                    sums are formed by the same sequential adds and written out.  A pixel that hits something gets a
-//                    32-byte record (hit point, sphere, normal) and an entry in the list of path pixels;
+//                    32-byte record (hit point, pixel, normal, sphere) in the compact list of path pixels;
 //   paths_kernel / paths_lbvh_kernel : persistent waves.  A TASK is one sample block of one path pixel (the reference's
 //                    TileAccumulator for that pixel, tile_buffer.rs:24-28: summed from zero in sample order).  A lane
 //                    takes a task, runs its samples in order with path regeneration (when a path ends, the lane adds it
@@ -116,13 +116,14 @@ __global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
     if (hit) {
         f3 pos0, nrm0;
         hit_geometry(sphere_at<ACCEL>(a, s_sph, h0.idx), r0.o, r0.d, h0.t, pos0, nrm0);
-        a.prim[2 * (size_t)pixel] = make_float4(pos0.x, pos0.y, pos0.z, __builtin_bit_cast(float, h0.idx));
-        a.prim[2 * (size_t)pixel + 1] = make_float4(nrm0.x, nrm0.y, nrm0.z, __builtin_bit_cast(float, wc0.disc));
         const int leader = __builtin_ctzll(hit_mask);
         uint32_t base = 0;
         if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&a.task_counters[0], (uint32_t)__builtin_popcountll(hit_mask));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        a.task_pixels[base + lane_rank(hit_mask)] = pixel;
+        const size_t at = (size_t)base + lane_rank(hit_mask);  // this pixel's place in the list of path pixels
+        a.prim[2 * at] = make_float4(pos0.x, pos0.y, pos0.z, __builtin_bit_cast(float, pixel));
+        a.prim[2 * at + 1] = make_float4(nrm0.x, nrm0.y, nrm0.z, __builtin_bit_cast(float, h0.idx));
+        a.prim_disc[at] = wc0.disc;
     } else {
         // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89); its block sums are
         // the same sequential adds the path lanes would make: one full block, and the shorter last one on the way
@@ -164,30 +165,23 @@ struct TaskState {
     uint32_t pixel, blk, s;  // s = samples of the block done so far
     float4 acc;              // the block sum
 };
-struct PrimaryHit {  // the pixel's record from primary_kernel
+struct PrimaryHit {  // a path pixel's record from primary_kernel
     f3 pos, nrm;
     int idx;
-    uint32_t disc;  // tests with discriminant >= 0 of the primary trace (statistics)
+    uint32_t pixel;
 };
 __device__ __forceinline__ uint32_t task_spp(const RenderArgs& a, uint32_t blk) {
     const uint32_t first = blk * a.sample_block;
     return (a.spp - first < a.sample_block) ? a.spp - first : a.sample_block;
 }
-__device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t pixel) {
-    const float4 r0 = a.prim[2 * (size_t)pixel], r1 = a.prim[2 * (size_t)pixel + 1];
+__device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t entry) {
+    const float4 r0 = a.prim[2 * (size_t)entry], r1 = a.prim[2 * (size_t)entry + 1];
     PrimaryHit h;
     h.pos = mk3(r0.x, r0.y, r0.z);
-    h.idx = __builtin_bit_cast(int, r0.w);
+    h.pixel = f32_bits(r0.w);
     h.nrm = mk3(r1.x, r1.y, r1.z);
-    h.disc = f32_bits(r1.w);
+    h.idx = __builtin_bit_cast(int, r1.w);
     return h;
-}
-__device__ __forceinline__ void begin_task(const RenderArgs& a, uint32_t task, TaskState& t) {
-    const uint32_t h = task / a.n_blocks;
-    t.blk = task - h * a.n_blocks;
-    t.pixel = a.task_pixels[h];
-    t.s = 0;
-    t.acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 // The block sum leaves the lane: the reference's merge of one TileAccumulator pixel (full_buffer.rs:107-125), deferred to
 // merge_kernel when the launch has several blocks.
@@ -235,7 +229,8 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
     PrimaryHit p0;  // of the task's pixel; three spheres leave the registers for it
     p0.pos = p0.nrm = mk3(0.0f, 0.0f, 0.0f);
     p0.idx = 0;
-    p0.disc = 0;
+    p0.pixel = 0;
+    uint32_t p0_disc = 0;  // tests with discriminant >= 0 of the primary trace (statistics only)
     uint32_t t_spp = 0, t_key = 0, t_base = 0;  // samples of the block, pixel key, first sample index of the block
     bool have = false, finished = false;
     // path state
@@ -249,8 +244,13 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
         uint32_t task = 0;
         const bool want = !have && !finished;
         if (take_task(pool, cursor, n_tasks, want, task)) {
-            begin_task(a, task, t);
-            p0 = load_primary(a, t.pixel);
+            const uint32_t entry = task / a.n_blocks;  // task = list entry x n_blocks + block
+            t.blk = task - entry * a.n_blocks;
+            p0 = load_primary(a, entry);
+            if (STATS) p0_disc = a.prim_disc[entry];
+            t.pixel = p0.pixel;
+            t.s = 0;
+            t.acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             t_spp = task_spp(a, t.blk);
             t_key = pixel_key(a.seed_lo, t.pixel);
             t_base = a.sample_base + t.blk * a.sample_block;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
             pos = p0.pos; nrm = p0.nrm; idx = p0.idx;
             contrib = mk3(1.0f, 1.0f, 1.0f);
             light = mk3(0.0f, 0.0f, 0.0f);
-            if (STATS) { n_traces++; n_disc += p0.disc; n_hits++; }
+            if (STATS) { n_traces++; n_disc += p0_disc; n_hits++; }
         } else if (want) {
             finished = true;
         }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
                     contrib = mk3(1.0f, 1.0f, 1.0f);
                     light = mk3(0.0f, 0.0f, 0.0f);
                     skey = sample_key(a.seed_hi, t_key, t_base + t.s);
-                    if (STATS) { n_traces++; n_disc += p0.disc; n_hits++; }
+                    if (STATS) { n_traces++; n_disc += p0_disc; n_hits++; }
                 }
             }
         }
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     // reason the shading point is not kept: the next ray's origin, pos + nrm * EPSILON (integrator.rs:80), goes straight
     // into the cursor, and the pixel's primary-hit record is read again for every sample (an L1/L2 hit).
     uint32_t* const s_task = reinterpret_cast<uint32_t*>(s_dyn) + (size_t)a.bvh.stack_depth * 256 + threadIdx.x;
-    auto task_word = [&](int k) -> uint32_t& { return s_task[k * 256]; };  // 0 pixel, 1 block, 2 samples done, 3..6 sum
+    auto task_word = [&](int k) -> uint32_t& { return s_task[k * 256]; };  // 0 list entry, 1 block, 2 samples done, 3..6 sum
     bool have = false, finished = false;
     uint32_t b = 0, skey = 0;
     f3 nrm = mk3(0.0f, 0.0f, 0.0f);
@@ -426,16 +426,16 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
     LbvhCursor cur;
     auto restart = [&]() {  // a sample starts at the pixel's primary hit
-        const uint32_t pixel = task_word(0), blk = task_word(1), done = task_word(2);
-        const PrimaryHit p0 = load_primary(a, pixel);
+        const uint32_t entry = task_word(0), blk = task_word(1), done = task_word(2);
+        const PrimaryHit p0 = load_primary(a, entry);
         b = 0;
         cur.o = p0.pos + p0.nrm * kEps;
         nrm = p0.nrm;
         idx = p0.idx;
         contrib = mk3(1.0f, 1.0f, 1.0f);
         light = mk3(0.0f, 0.0f, 0.0f);
-        skey = sample_key(a.seed_hi, pixel_key(a.seed_lo, pixel), a.sample_base + blk * a.sample_block + done);
-        if (STATS) { n_traces++; n_disc += p0.disc; n_hits++; }
+        skey = sample_key(a.seed_hi, pixel_key(a.seed_lo, p0.pixel), a.sample_base + blk * a.sample_block + done);
+        if (STATS) { n_traces++; n_disc += a.prim_disc[entry]; n_hits++; }
     };
     cursor_begin(cur, mk3(0, 0, 0), mk3(0, 0, 1));
     cur.cur = kCursorDone;
@@ -457,9 +457,9 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
             uint32_t task = 0;
             const bool want = waiting && !have;
             if (take_task(pool, cursor, n_tasks, want, task)) {
-                const uint32_t h = task / a.n_blocks;
-                task_word(0) = a.task_pixels[h];
-                task_word(1) = task - h * a.n_blocks;
+                const uint32_t entry = task / a.n_blocks;
+                task_word(0) = entry;
+                task_word(1) = task - entry * a.n_blocks;
                 task_word(2) = 0u;
                 task_word(3) = task_word(4) = task_word(5) = task_word(6) = 0u;  // the block sum starts at +0
                 have = true;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                         const uint32_t done_now = task_word(2) + 1u, blk = task_word(1);
                         if (done_now >= task_spp(a, blk)) {
                             TaskState t;
-                            t.pixel = task_word(0);
+                            t.pixel = f32_bits(a.prim[2 * (size_t)task_word(0)].w);
                             t.blk = blk;
                             t.s = done_now;
                             t.acc = acc;
