@@ -237,7 +237,8 @@ def main():
         _capi.check(rt._ctx, _capi.lib.ir_bind_accumulator(rt._ctx, sums.data_ptr(), counts.data_ptr(), W, H))
         _capi.check(rt._ctx, _capi.lib.ir_set_stream(rt._ctx, torch.cuda.current_stream().cuda_stream))
 
-    kernel_ms = []
+    kernel_ms = []  # (device ms of all launches of a step, launches)
+    paths_ms = []   # device ms of the path kernel of a step's last launch
 
     def step():
         if native is not None:
@@ -247,6 +248,7 @@ def main():
             return
         rt.render(scene, W, H, False, spp=spp)  # blocks until the launches are done
         kernel_ms.append(rt.last_kernel_ms())
+        paths_ms.append(rt.last_paths_kernel_ms())
         if world > 1 and args.rehearse_one_gpu:
             hs, hc = sums.cpu(), counts.cpu()
             dist.reduce(hs, dst=0, op=dist.ReduceOp.SUM)
@@ -271,6 +273,7 @@ def main():
         step()
     fence()
     kernel_ms.clear()
+    paths_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -285,6 +288,7 @@ def main():
         exchange_info = {"how": exchange}
         if native is not None:
             kernel_ms.append(rt.last_kernel_ms())  # the last step's launches (the steps are identical)
+            paths_ms.append(rt.last_paths_kernel_ms())
             exchange_info["last_exchange_ms"] = native.last_ms()
             exchange_info["bytes_per_rank"] = (int(_capi.lib.ir_tile_payload_bytes(W, H, rank, world)) if partition == "tiles"
                                                else W * H * 20)
@@ -299,18 +303,22 @@ def main():
     if rank == 0:
         ms = [m for m, _ in kernel_ms]
         launches = sum(n for _, n in kernel_ms)
-        avg_launch_ms = sum(ms) / max(launches, 1)  # HIP events around the launches, on the stream they run on
+        launches_per_step = max(1, kernel_ms[0][1])
+        avg_sequence_ms = sum(ms) / max(launches, 1)  # primary pass + path kernel + merge of one launch, HIP events
+        # The dominant kernel is the persistent path kernel; HIP events right around it, on the stream it runs on
+        avg_launch_ms = sum(paths_ms) / max(len(paths_ms), 1)
         # algorithmic flops per sample from the kernel's own counters (untimed extra render, same workload)
         if world > 1:
             rt.set_partition(_capi.IR_PARTITION_NONE, 0, 1)
         rt.enable_stats()
         rt.render(scene, W, H, False, spp=spp)
         st = rt.get_stats()
+        prof = rt.get_lane_profile()
         info = rt.get_accel_info()
         lbvh = info["accel"] == _capi.IR_ACCEL_LBVH
         ast = rt.get_accel_stats() if lbvh else None
         F = flops_per_sample(st, ast)
-        samples_per_launch = W * H * spp / max(1, kernel_ms[0][1]) / (world if partition == "tiles" else 1)
+        samples_per_launch = W * H * spp / launches_per_step / (world if partition == "tiles" else 1)
         achieved = samples_per_launch * F / (avg_launch_ms * 1e-3) / 1e12
         total_samples = work_ranks * W * H * spp * args.steps
         # Counter-derived figures of this same launch (C2 at 1024 spp) from the round's committed rocprofv3 PMC passes
@@ -362,15 +370,20 @@ def main():
                 "executed_fp_tflops": executed_tf,
                 "lane_utilisation": lane_util,
                 "pmc_source": pmc_source,
-                "kernel": "render_kernel<%s, false>" % ("lbvh" if lbvh else "linear"),
+                "kernel": "paths_lbvh_kernel<false, false>" if lbvh else "paths_kernel<false, false>",
                 "avg_launch_ms": avg_launch_ms,
-                "launches_per_step": kernel_ms[0][1],
+                "avg_launch_sequence_ms": avg_sequence_ms,
+                "launches_per_step": launches_per_step,
+                "loop_lane_utilisation": prof[list(prof)[0]][1] / max(1, 64 * prof[list(prof)[0]][0]),
                 "algorithmic_flops_per_sample": F,
                 "mean_traces_per_sample": st["traces"] / st["samples"],
                 "brute_force_equivalent_flops_per_sample": flops_per_sample(st, None),
                 "note": "FP32 vector peak 157.3 TF assumes FMA; this path is bit-exact (no FMA contraction), so its "
                         "issue ceiling is 78.6 TF (one flop per lane-op); algorithmic flops count the primary ray "
-                        "per sample although the kernel shares it across the samples of a pixel; executed_fp_tflops = "
+                        "per sample although the primary pass evaluates it once per pixel; avg_launch_ms = the persistent "
+                        "path kernel alone (avg_launch_sequence_ms adds the primary pass and the merge); "
+                        "loop_lane_utilisation = lanes holding a task at the top of the path loop / 64, counted by the "
+                        "kernel's statistics build; executed_fp_tflops = "
                         "FP32 ops the kernel actually issued (ADD + MUL + TRANS + 2 FMA wave-instructions x 64 lanes x "
                         "lane utilisation, from the PMC passes) / the live launch time",
             },

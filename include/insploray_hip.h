@@ -272,6 +272,9 @@ double ir_last_render_seconds(const ir_context* ctx);
 /* Device time of the integrator kernel launches of the last render (HIP events on the launch stream), ms,
  * and how many launches that was. */
 double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches);
+/* Device time of the path kernel alone (the persistent kernel that runs every sample block of every pixel whose primary
+ * ray hits something; the dominant kernel) in the LAST launch of the last render, ms; 0 when that render launched none. */
+double ir_last_paths_kernel_ms(const ir_context* ctx);
 /* Samples per pixel accumulated by this context since the last reset. */
 uint32_t ir_samples_accumulated(const ir_context* ctx);
 /* Checkpoint restore: after ir_set_radiance with a stored accumulator, tell the context how many samples per pixel

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "ir_get_size": (C.c_int, [ctx_p, c_u32_p, c_u32_p]),
     "ir_last_render_seconds": (C.c_double, [ctx_p]),
     "ir_last_kernel_ms": (C.c_double, [ctx_p, c_u32_p]),
+    "ir_last_paths_kernel_ms": (C.c_double, [ctx_p]),
     "ir_samples_accumulated": (C.c_uint32, [ctx_p]),
     "ir_set_samples_accumulated": (C.c_int, [ctx_p, C.c_uint32]),
     "ir_device_radiance": (C.c_void_p, [ctx_p]),

@@ -328,6 +328,8 @@ int ir_create(ir_context** out_ctx, int device) {
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev_p0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev_p1)) != hipSuccess) return bail("hipEventCreate", e);
     if (init_noalloc_scratch(device, &e) != IR_OK) return bail("hipGetSymbolAddress(static scratch)", e);
     if ((e = pt::init_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
     if ((e = pt::init_wavefront_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
@@ -352,6 +354,8 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_sky_marginal_guide); release(ctx->d_sky_cond_guide);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_p0) (void)hipEventDestroy(ctx->ev_p0);
+    if (ctx->ev_p1) (void)hipEventDestroy(ctx->ev_p1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -583,6 +587,7 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         return fail(ctx, IR_ELIMIT, "%s: %ux%u exceeds the supported frame size", who, width, height);
     IR_TRY(use_device(ctx));
     ctx->events_recorded = false;
+    ctx->paths_timed = false;
     ctx->last_launches = 0;
     ctx->stats_valid = false;
     ctx->output_combined = false;
@@ -764,7 +769,8 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         const uint32_t now = (spp - done < chunk) ? (spp - done) : chunk;
         a.spp = now;
         a.sample_base = (uint32_t)(base + done);
-        IR_HIP(ctx, pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream));
+        IR_HIP(ctx, pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream, ctx->ev_p0, ctx->ev_p1));
+        ctx->paths_timed = true;
         done += now;
         ctx->last_launches++;
     }
@@ -944,6 +950,15 @@ double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches) {
     if (hipEventSynchronize(ctx->ev1) != hipSuccess) return 0.0;
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return 0.0;
+    return (double)ms;
+}
+
+double ir_last_paths_kernel_ms(const ir_context* ctx) {
+    if (!ctx || !ctx->paths_timed) return 0.0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0.0;
+    if (hipEventSynchronize(ctx->ev_p1) != hipSuccess) return 0.0;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_p0, ctx->ev_p1) != hipSuccess) return 0.0;
     return (double)ms;
 }
 

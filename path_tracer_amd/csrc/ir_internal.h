@@ -26,7 +26,9 @@ struct ir_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around all launches of a render call
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // around the path kernel of its last launch
+    bool paths_timed = false;
     mutable std::string err;
 
     // scene (host copies kept so that the per-sphere shading table can be rebuilt when either side changes)

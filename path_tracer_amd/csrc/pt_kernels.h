@@ -138,7 +138,9 @@ enum { kAccelLinear = 0, kAccelLbvh = 1 };
 constexpr uint32_t kNumStats = 15;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests, 8 x lane profile
 // scratch the launch needs besides `partials`: prim (32 B per pixel), prim_disc (4 B per pixel), task_counters (8 B)
 constexpr size_t kPrimBytesPerPixel = 32, kTaskBytesPerPixel = 4, kTaskCounterBytes = 256;
-hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream);
+// paths_begin / paths_end (may be null): events recorded right around the persistent path kernel, the dominant one
+hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream, hipEvent_t paths_begin = nullptr,
+                         hipEvent_t paths_end = nullptr);
 hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream);
 hipError_t launch_resolve(const float4* sum, const uint32_t* counts, uint32_t* argb, size_t n, hipStream_t stream);
 // exact-math self test (pt_selftest.hip): adds mismatch counts into d_bad[kNumSelftests] (zeroed by the caller)

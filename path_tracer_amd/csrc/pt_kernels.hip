@@ -138,8 +138,10 @@ __global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
         }
         if (a.partials) {
             const size_t npix = (size_t)a.w * a.h;
-            for (uint32_t blk = 0; blk < a.n_blocks; ++blk) a.partials[(size_t)blk * npix + pixel] = blk < n_full ? acc : last;
+            for (uint32_t blk = 0; blk < n_full; ++blk) a.partials[(size_t)blk * npix + pixel] = acc;
+            if (rem) a.partials[(size_t)n_full * npix + pixel] = last;  // (n_blocks = n_full + 1 then)
         } else {  // a single block: merged right here
+            if (!n_full) acc = last;
             float4 t = a.sum[pixel];
             t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
             a.sum[pixel] = t;
@@ -707,7 +709,7 @@ hipError_t persistent_grid(const void* kernel, size_t lds, uint64_t max_tasks, u
 
 }  // namespace
 
-hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStream_t stream) {
+hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStream_t stream, hipEvent_t paths_begin, hipEvent_t paths_end) {
     const uint32_t owned = owned_tiles(a_in.n_tiles, a_in.tile_rank, a_in.tile_world);
     if (owned == 0 || a_in.spp == 0) return hipSuccess;
     RenderArgs a = a_in;
@@ -744,8 +746,10 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     e = persistent_grid(paths, lds, max_tasks, &grid);
     if (e != hipSuccess) return e;
     void* params[] = {(void*)&a};
+    if (paths_begin && (e = hipEventRecord(paths_begin, stream)) != hipSuccess) return e;
     e = hipLaunchKernel(paths, dim3(grid), block, params, lds, stream);
     if (e != hipSuccess) return e;
+    if (paths_end && (e = hipEventRecord(paths_end, stream)) != hipSuccess) return e;
     if (a.n_blocks > 1) {
         hipLaunchKernelGGL(merge_kernel, dim3(a.wgs_per_layer), block, 0, stream, a);
         e = hipGetLastError();

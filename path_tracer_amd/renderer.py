@@ -208,6 +208,10 @@ class RayTracer:
         ms = _capi.lib.ir_last_kernel_ms(self._ctx, C.byref(n))
         return ms, n.value
 
+    def last_paths_kernel_ms(self):
+        """Device time of the path kernel of the last launch (ir_last_paths_kernel_ms)."""
+        return float(_capi.lib.ir_last_paths_kernel_ms(self._ctx))
+
     def samples_accumulated(self):
         return int(_capi.lib.ir_samples_accumulated(self._ctx))
 
