@@ -11,6 +11,8 @@ pub const IR_OK: c_int = 0;
 pub const IR_PARTITION_NONE: c_int = 0;
 pub const IR_PARTITION_TILES: c_int = 1;
 pub const IR_PARTITION_SAMPLES: c_int = 2;
+pub const IR_SAMPLE_BLOCK_AUTO: u32 = 0;
+pub const IR_COMM_ID_BYTES: usize = 128;
 
 extern "C" {
     pub fn ir_abi_version() -> u32;
@@ -41,10 +43,24 @@ extern "C" {
     pub fn ir_set_integrator(ctx: *mut ir_context, bounces: u32, max_compulsory_bounces: u32, seed: u64) -> c_int;
     pub fn ir_set_schedule(ctx: *mut ir_context, schedule: c_int, max_paths: u32) -> c_int;
     pub fn ir_set_sample_block(ctx: *mut ir_context, samples_per_block: u32) -> c_int;
+    pub fn ir_get_sample_block(ctx: *mut ir_context, width: u32, height: u32, spp: u32, out_block: *mut u32) -> c_int;
     pub fn ir_set_partition(ctx: *mut ir_context, mode: c_int, rank: u32, world: u32) -> c_int;
+    // exchange step (RCCL inside the library; renderer.rs:152-159 is the single-process merge it scales out)
+    pub fn ir_comm_unique_id(out_id: *mut u8) -> c_int;
+    pub fn ir_comm_init(ctx: *mut ir_context, unique_id: *const u8, rank: u32, world: u32) -> c_int;
+    pub fn ir_comm_destroy(ctx: *mut ir_context) -> c_int;
+    pub fn ir_combine(ctx: *mut ir_context, root: u32) -> c_int;
+    pub fn ir_combine_async(ctx: *mut ir_context, root: u32) -> c_int;
+    pub fn ir_combine_wait(ctx: *mut ir_context) -> c_int;
+    pub fn ir_last_combine_ms(ctx: *const ir_context) -> c_double;
+    pub fn ir_tile_payload_bytes(width: u32, height: u32, rank: u32, world: u32) -> usize;
+    pub fn ir_pack_owned_tiles(ctx: *mut ir_context, d_out: *mut c_void, bytes: usize) -> c_int;
+    pub fn ir_unpack_tiles(ctx: *mut ir_context, d_in: *const c_void, bytes: usize, rank: u32, world: u32) -> c_int;
     pub fn ir_render(ctx: *mut ir_context, width: u32, height: u32, spp: u32, accumulate: c_int) -> c_int;
     pub fn ir_render_async(ctx: *mut ir_context, width: u32, height: u32, spp: u32, accumulate: c_int) -> c_int;
     pub fn ir_synchronize(ctx: *mut ir_context) -> c_int;
+    pub fn ir_render_noalloc(ctx: *mut ir_context, width: u32, height: u32, spp: u32, accumulate: c_int,
+                             d_sum_rgba: *mut c_void, d_counts: *mut c_void) -> c_int;
     pub fn ir_get_output_argb(ctx: *mut ir_context, out: *mut u32, n: usize) -> c_int;
     pub fn ir_get_radiance(ctx: *mut ir_context, sum_rgba: *mut c_float, counts: *mut u32, n: usize) -> c_int;
     pub fn ir_set_radiance(ctx: *mut ir_context, sum_rgba: *const c_float, counts: *const u32, n: usize) -> c_int;
@@ -52,6 +68,7 @@ extern "C" {
     pub fn ir_get_size(ctx: *const ir_context, width: *mut u32, height: *mut u32) -> c_int;
     pub fn ir_last_render_seconds(ctx: *const ir_context) -> c_double;
     pub fn ir_last_kernel_ms(ctx: *const ir_context, n_launches: *mut u32) -> c_double;
+    pub fn ir_last_paths_kernel_ms(ctx: *const ir_context) -> c_double;
     pub fn ir_samples_accumulated(ctx: *const ir_context) -> u32;
     pub fn ir_set_samples_accumulated(ctx: *mut ir_context, samples: u32) -> c_int;
     pub fn ir_device_radiance(ctx: *mut ir_context) -> *mut c_void;
@@ -60,6 +77,7 @@ extern "C" {
     pub fn ir_enable_stats(ctx: *mut ir_context, enable: c_int) -> c_int;
     pub fn ir_get_stats(ctx: *mut ir_context, out5: *mut u64) -> c_int;
     pub fn ir_get_accel_stats(ctx: *mut ir_context, out2: *mut u64) -> c_int;
+    pub fn ir_get_lane_profile(ctx: *mut ir_context, out8: *mut u64) -> c_int;
     pub fn ir_selftest_exact_math(ctx: *mut ir_context, out_mismatches: *mut u64, n_out: u32, log2_random_samples: u32) -> c_int;
     pub fn ir_exr_load(path: *const c_char, out_rgb: *mut *mut c_float, out_w: *mut u32, out_h: *mut u32) -> c_int;
     pub fn ir_exr_last_error() -> *const c_char;
