@@ -246,6 +246,11 @@ def main():
             rt.render(scene, W, H, False, spp=spp, blocking=False)
             native.combine_async(0)
             return
+        if world == 1:
+            # enqueue only: the K steps queue up on the stream and the fence below waits for all of them, so the GPU does
+            # not idle while the host comes back from a synchronisation and issues the next step's four launches
+            rt.render(scene, W, H, False, spp=spp, blocking=False)
+            return
         rt.render(scene, W, H, False, spp=spp)  # blocks until the launches are done
         kernel_ms.append(rt.last_kernel_ms())
         paths_ms.append(rt.last_paths_kernel_ms())
@@ -261,8 +266,9 @@ def main():
             dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
-        if native is not None:
+        if native is not None or world == 1:
             rt.synchronize()
+        if native is not None:
             native.wait()
         torch.cuda.synchronize()
         if world > 1:
@@ -283,6 +289,9 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    if world == 1:
+        kernel_ms.append(rt.last_kernel_ms())  # the last step's launches (the steps are identical)
+        paths_ms.append(rt.last_paths_kernel_ms())
     exchange_info = None
     if world > 1:
         exchange_info = {"how": exchange}

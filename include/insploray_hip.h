@@ -156,9 +156,9 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
  * sums are merged into the accumulator in block order.  Blocks are independent until the merge, which is what lets
  * one call fill the GPU.  On a zeroed accumulator a call with spp <= samples_per_block is bit-identical to spp
  * successive reference-style 1-sample calls.
- * IR_SAMPLE_BLOCK_AUTO (0): 128, halved (not below 8) until the launch has at least 4096 x 256 (pixel, block) tasks: a
+ * IR_SAMPLE_BLOCK_AUTO (0): 128, halved (not below 8) until the launch has at least 8192 x 256 (pixel, block) tasks: a
  * small frame at a low sample count otherwise lasts as long as its longest block runs on one lane (the reference's own
- * headless case, 800x450 at 64 spp: 16-sample blocks render it in half the time of one 64-sample block per pixel).  A pure
+ * headless case, 800x450 at 64 spp: 8-sample blocks render it in 0.4 of the time of one 64-sample block per pixel).  A pure
  * function of the pixels this rank owns — 4096 per 64x64 tile — and spp; ir_get_sample_block returns what a render of
  * that shape would use, so that a caller (or a checker) can reproduce the order of the sums. */
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);
@@ -238,11 +238,14 @@ int ir_synchronize(ir_context* ctx);
  * d_sum_rgba = width*height float4, d_counts = width*height u32, on the context's device; accumulate == 0 zeroes them
  * first and restarts the sample sequence at 0, otherwise the samples continue the context's sequence
  * (ir_samples_accumulated) as ir_render's would.  The context's own accumulator and size are not touched.  The block
- * sums of a launch (ir_set_sample_block) go to a static 128 MiB device array instead of an allocated buffer, which
- *   - limits the frame to 4 194 304 pixels (two block sums must fit; larger frames: IR_ELIMIT), launches are cut so
- *     that their block sums fit (results do not depend on the cut);
- *   - is shared by every context on that GPU and keeps the last call's contents (every entry a launch reads was
- *     written by that launch, nothing needs clearing): calls that overlap on one GPU race — serialise them.
+ * launch scratch (primary-hit records, task queue counters, the block sums of a launch, ir_set_sample_block) is a static
+ * 160 MiB device array instead of allocated buffers, which
+ *   - limits the frame to 2 467 109 pixels (68 B per pixel: the records and two block sums must fit; larger frames:
+ *     IR_ELIMIT; 1920x1080 fits, 3840x2160 does not), launches are cut so that their block sums fit (results do not
+ *     depend on the cut);
+ *   - is shared by every context on that GPU and keeps the last call's contents (the task counters are zeroed by every
+ *     launch, every other entry a launch reads was written by that launch): calls that overlap on one GPU race —
+ *     serialise them.
  * The scene's device tables must be current: after changing the scene, the sky or the closest-hit structure call
  * ir_render once (spp 0 is enough), else IR_ESTATE.  IR_SCHEDULE_WAVEFRONT and ir_enable_stats allocate: IR_ESTATE.
  * Returns after enqueueing on the context's stream; ir_synchronize waits. */

@@ -130,12 +130,12 @@ int selected_accel(const ir_context* ctx) {
 }
 
 // Samples per accumulation block of a render when ir_set_sample_block selected IR_SAMPLE_BLOCK_AUTO: 128, halved (not
-// below 8) until the launch has at least kAutoMinWorkgroups x 256 (pixel, block) tasks.  A small launch lasts as long as
-// its longest task runs on one lane (C1, 800x450x64: 0.81 ms of path kernel with one 64-sample task per pixel, 0.38 ms
-// with four tasks of 16); shorter tasks still cost a task switch each (8-sample tasks: slower again).  A pure function of
-// the workgroups-worth of pixels this rank owns and spp, so that a caller (and the oracle in the tests) can reproduce the
-// sum order.
-constexpr uint32_t kAutoMinWorkgroups = 4096;
+// below 8) until the launch has at least kAutoMinWorkgroups x 256 (pixel, block) tasks, about five per resident lane.  A
+// small launch lasts as long as its longest task runs on one lane and then drains for about one more task (C1,
+// 800x450x64: 0.82 ms of path kernel with one 64-sample task per pixel, 0.37 ms with four tasks of 16, 0.32 ms with eight
+// of 8; 4-sample tasks are no faster: every task costs a switch).  A pure function of the workgroups-worth of pixels this
+// rank owns and spp, so that a caller (and the oracle in the tests) can reproduce the sum order.
+constexpr uint32_t kAutoMinWorkgroups = 8192;
 uint32_t auto_sample_block(uint32_t wgs_per_block, uint32_t spp) {
     uint32_t sb = 128;
     while (sb > 8 && (uint64_t)wgs_per_block * ((spp + sb - 1) / sb) < kAutoMinWorkgroups) sb /= 2;
@@ -148,7 +148,7 @@ uint32_t auto_sample_block(uint32_t wgs_per_block, uint32_t spp) {
 // ir_create asks each device for ITS copy's address (hipGetSymbolAddress) and keeps it in g_noalloc_scratch[device].
 constexpr size_t kNoAllocScratchBytes = 160ull << 20;
 // per pixel: primary record 32 B + task list entry 4 B + two block sums of 16 B (a launch of at least two blocks)
-constexpr size_t kNoAllocMaxPixels = (kNoAllocScratchBytes - 4096) / (pt::kPrimBytesPerPixel + pt::kTaskBytesPerPixel + 2 * sizeof(float4));
+constexpr size_t kNoAllocMaxPixels = (kNoAllocScratchBytes - 2 * pt::kTaskCounterBytes) / (pt::kPrimBytesPerPixel + pt::kTaskBytesPerPixel + 2 * sizeof(float4));
 __device__ __align__(256) float4 g_noalloc_scratch_array[kNoAllocScratchBytes / sizeof(float4)];
 constexpr int kMaxDevices = 64;
 void* g_noalloc_scratch[kMaxDevices] = {nullptr};
@@ -610,10 +610,16 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     } else {
         IR_TRY(prepare_scene(ctx));
     }
+    // renderer.rs:99-103: a non-accumulating render starts from a zero accumulator.  When the first launch of this call
+    // visits every pixel anyway (task schedule, the whole frame owned), its primary pass writes the zeros: two fills less.
+    const bool wavefront = ctx->schedule == IR_SCHEDULE_WAVEFRONT && !ctx->stats_enabled;
+    const bool owns_all = !(ctx->part_mode == IR_PARTITION_TILES && ctx->world > 1);
+    const bool fresh_in_kernel = !accumulate && spp != 0 && n != 0 && !wavefront && owns_all;
     if (!accumulate) {
-        // renderer.rs:99-103
-        IR_HIP(ctx, hipMemsetAsync(sum, 0, n * sizeof(float4), ctx->stream));
-        IR_HIP(ctx, hipMemsetAsync(counts, 0, n * sizeof(uint32_t), ctx->stream));
+        if (!fresh_in_kernel) {
+            IR_HIP(ctx, hipMemsetAsync(sum, 0, n * sizeof(float4), ctx->stream));
+            IR_HIP(ctx, hipMemsetAsync(counts, 0, n * sizeof(uint32_t), ctx->stream));
+        }
         ctx->samples_done = 0;
     }
     if (spp == 0) return IR_OK;
@@ -751,17 +757,23 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         a.prim_disc = (uint32_t*)(base + off);
         off = (off + n * pt::kTaskBytesPerPixel + pt::kTaskCounterBytes - 1) / pt::kTaskCounterBytes * pt::kTaskCounterBytes;
         a.task_counters = (uint32_t*)(base + off);
+        a.task_counters_next = nullptr;  // the array is shared by every context of the device: zeroed per launch
         off += pt::kTaskCounterBytes;
         a.partials = (float4*)(base + off);
     } else {
         if (max_blocks > 1) IR_TRY(ensure(ctx, ctx->d_partials, (size_t)max_blocks * n * sizeof(float4)));
         IR_TRY(ensure(ctx, ctx->d_prim, n * pt::kPrimBytesPerPixel));
         IR_TRY(ensure(ctx, ctx->d_task_pixels, n * pt::kTaskBytesPerPixel));
-        IR_TRY(ensure(ctx, ctx->d_task_counters, pt::kTaskCounterBytes));
+        if (!ctx->d_task_counters.p || !ctx->task_counters_clean) {
+            // two pairs of counters used in turn: a launch's primary pass zeroes the pair of the next launch
+            IR_TRY(ensure(ctx, ctx->d_task_counters, pt::kTaskCounterBytes));
+            IR_HIP(ctx, hipMemsetAsync(ctx->d_task_counters.p, 0, pt::kTaskCounterBytes, ctx->stream));
+            ctx->task_counters_clean = true;
+            ctx->launch_parity = 0;
+        }
         a.partials = (float4*)ctx->d_partials.p;
         a.prim = (float4*)ctx->d_prim.p;
         a.prim_disc = (uint32_t*)ctx->d_task_pixels.p;
-        a.task_counters = (uint32_t*)ctx->d_task_counters.p;
     }
     IR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     uint32_t done = 0;
@@ -769,7 +781,18 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         const uint32_t now = (spp - done < chunk) ? (spp - done) : chunk;
         a.spp = now;
         a.sample_base = (uint32_t)(base + done);
-        IR_HIP(ctx, pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream, ctx->ev_p0, ctx->ev_p1));
+        a.fresh = (fresh_in_kernel && done == 0) ? 1u : 0u;
+        if (!noalloc && owned_wgs != 0) {  // (a rank that owns no tile launches nothing: the pairs stay as they are)
+            uint32_t* const pairs = (uint32_t*)ctx->d_task_counters.p;
+            a.task_counters = pairs + ctx->launch_parity * pt::kTaskCounterPairStride;
+            a.task_counters_next = pairs + (ctx->launch_parity ^ 1u) * pt::kTaskCounterPairStride;
+            ctx->launch_parity ^= 1u;
+        }
+        const hipError_t le = pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream, ctx->ev_p0, ctx->ev_p1);
+        if (le != hipSuccess) {
+            ctx->task_counters_clean = false;  // whatever ran may have left the counters anywhere
+            return fail(ctx, IR_EDEVICE, "%s: launch failed: %s", who, hipGetErrorString(le));
+        }
         ctx->paths_timed = true;
         done += now;
         ctx->last_launches++;

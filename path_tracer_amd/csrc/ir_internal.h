@@ -68,6 +68,8 @@ struct ir_context {
     uint32_t bounces = 5, rr_start = 2;
     uint32_t sample_block = 128;  // IR_SAMPLE_BLOCK_AUTO (0): chosen per render from the launch grid
     irx::DeviceBuf d_partials;
+    bool task_counters_clean = false;  // both counter pairs of d_task_counters are zero / being kept zero by the launches
+    uint32_t launch_parity = 0;        // which pair the next launch uses
     irx::DeviceBuf d_prim, d_task_pixels, d_task_counters;  // launch scratch of the primary pass / task dispenser
     // wavefront schedule: path queues and per-sample values (allocated on first use)
     int schedule = IR_SCHEDULE_AUTO;

@@ -39,12 +39,16 @@ struct RenderArgs {
     uint32_t seed_lo, seed_hi;
     uint32_t spp, sample_base;
 
-    // Samples [sample_base, sample_base + spp) of a launch are cut into blocks of sample_block samples; one workgroup
-    // sums one block of its 16x16 pixels from zero (in sample order), the block sums are merged in block order.
-    // partials: n_blocks x (w*h) float4 scratch (unused when the launch has a single block).
+    // Samples [sample_base, sample_base + spp) of a launch are cut into blocks of sample_block samples; a task sums one
+    // block of one path pixel from zero (in sample order), the block sums are merged in block order.
+    // partials: block sums by task id (list entry x n_blocks + block): room for (owned pixels) x n_blocks float4 (unused
+    // when the launch has a single block).  A lane's tasks are neighbours in this array, so are the stores of a wave.
     uint32_t sample_block;
     uint32_t n_blocks, wgs_per_layer;  // filled in by launch_render (wgs_per_layer = 16 x owned tiles)
     float4* partials;
+    // 1: the accumulator starts at zero with this launch (renderer.rs:99-103); the primary pass writes instead of adding,
+    // which saves the two fills of a non-accumulating render.  Only valid when the launch owns every pixel.
+    uint32_t fresh;
 
     float4* sum;       // running radiance sum (rgb) + sample weight (a)
     uint32_t* counts;  // samples per pixel
@@ -52,7 +56,13 @@ struct RenderArgs {
     // Launch scratch of the primary pass and the task dispenser (pt_kernels.hip "Schedule"):
     float4* prim;             // list of path pixels (primary ray hits): [2e] = (hit point, pixel bits), [2e+1] = (normal, sphere index bits)
     uint32_t* prim_disc;      // per list entry: tests with discriminant >= 0 of the primary trace (statistics)
-    uint32_t* task_counters;  // [0] = list length, [1] = next unclaimed task (task = list entry * n_blocks + block)
+    // one set of counters: word 0 = list length; word (1 + q) * kTaskCounterStride = cursor of task queue q
+    // (task = list entry * n_blocks + block; queue q holds the ids [q, q + 1) * task_queue_span(n_tasks, n_queues))
+    uint32_t* task_counters;
+    uint32_t n_queues;  // queues in use, a power of two <= kTaskQueues (launch_render: one when tasks are long and many)
+    // The other set of counters, zeroed by this launch's primary pass for the next launch (the context alternates between
+    // two sets, which saves a fill per launch), or nullptr when the caller zeroes task_counters itself.
+    uint32_t* task_counters_next;
 
     // tile partition: this launch renders tiles t = tile_rank + k * tile_world, k = 0 .. n_owned_tiles-1
     uint32_t tiles_x, n_tiles, tile_rank, tile_world;
@@ -136,8 +146,18 @@ hipError_t launch_wavefront(const WfArgs& a, int accel, uint32_t per_batch, uint
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 enum { kAccelLinear = 0, kAccelLbvh = 1 };
 constexpr uint32_t kNumStats = 15;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests, 8 x lane profile
-// scratch the launch needs besides `partials`: prim (32 B per pixel), prim_disc (4 B per pixel), task_counters (8 B)
-constexpr size_t kPrimBytesPerPixel = 32, kTaskBytesPerPixel = 4, kTaskCounterBytes = 256;
+// Task queues of the persistent path kernels (pt_kernels.hip take_task): counters 128 bytes apart, two sets of them.
+#ifndef IR_TASK_QUEUES
+#define IR_TASK_QUEUES 16  // (tools/ build variants with other counts)
+#endif
+constexpr uint32_t kTaskQueues = IR_TASK_QUEUES, kTaskCounterStride = 32;
+constexpr uint32_t kTaskCounterPairStride = (1 + kTaskQueues) * kTaskCounterStride;  // words per set
+__host__ __device__ inline uint32_t task_queue_span(uint32_t n_tasks, uint32_t n_queues) {  // ids per queue: whole chunks of 64
+    return ((n_tasks + n_queues - 1) / n_queues + 63u) / 64u * 64u;
+}
+// scratch the launch needs besides `partials`: prim (32 B per pixel), prim_disc (4 B per pixel), task_counters
+constexpr size_t kPrimBytesPerPixel = 32, kTaskBytesPerPixel = 4, kTaskCounterBytes = 2 * kTaskCounterPairStride * 4;
+static_assert(kTaskCounterBytes % 128 == 0, "the no-alloc carve aligns on this");
 // paths_begin / paths_end (may be null): events recorded right around the persistent path kernel, the dominant one
 hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t stream, hipEvent_t paths_begin = nullptr,
                          hipEvent_t paths_end = nullptr);

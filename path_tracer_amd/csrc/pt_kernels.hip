@@ -51,8 +51,8 @@ __device__ __forceinline__ float4 sphere_at(const Args& a, const float4* s_sph, 
 //                    takes a task, runs its samples in order with path regeneration (when a path ends, the lane adds it
 //                    to the block sum and restarts at the pixel's primary hit with the next sample index), writes the
 //                    block sum and takes the next task — lanes never wait for the slowest pixel of their wave or of
-//                    their workgroup, and a frame of any size fills the chip.  Waves draw tasks in chunks of 64 from one
-//                    global counter (one atomic per 64 tasks) and hand them to their lanes by ballot + mbcnt;
+//                    their workgroup, and a frame of any size fills the chip.  Waves draw tasks in chunks of 64 from
+//                    16 queues (one atomic per 64 tasks) and hand them to their lanes by ballot + mbcnt;
 //   merge_kernel   : block sums into the accumulator, in block order (full_buffer.rs:107-125).
 // Which lane runs a task never enters the arithmetic: results equal the one-lane-per-pixel formulation bit for bit.
 // ----------------------------------------------------------------------------------------------------
@@ -62,17 +62,25 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {  // set
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Wave-uniform task dispenser.  `want`: this lane asks for a task.  Returns true and the task id when it got one; false
-// when the queue is exhausted (or the lane did not ask).  Every lane of the wave must call it together.
+// Wave-uniform task dispenser.  The task ids [0, n_tasks) are cut into kTaskQueues contiguous ranges with a cursor each
+// (pt_kernels.h): atomics on ONE address are served one after the other chip-wide (measured: 3 .. 10 ns each, so the 8 192
+// first requests of a launch alone kept its last wave waiting for up to 80 us, and 4-sample blocks ran at a third of the
+// rate of 16-sample blocks).  A wave starts on the queue of its workgroup (blockIdx mod kTaskQueues), draws chunks of 64
+// ids from it and moves on to the next queue when one is exhausted; after kTaskQueues exhausted queues it is done.
+// `want`: this lane asks for a task.  Every lane of the wave must call it together.
+enum { kTaskNone = 0, kTaskGot = 1, kTaskExhausted = -1 };  // kTaskNone: not asked, or ask again (the chunk was short)
 struct TaskPool {
-    uint32_t next = 0, end = 0;  // wave-uniform: unclaimed ids [next, end) of the wave's current chunk
+    uint32_t next = 0, end = 0;     // wave-uniform: unclaimed ids [next, end) of the wave's current chunk
+    uint32_t queue = 0, tried = 0;  // current queue; queues this wave has found exhausted
 };
-__device__ __forceinline__ bool take_task(TaskPool& pool, uint32_t* cursor, uint32_t n_tasks, bool want, uint32_t& task) {
+#ifdef IR_OLD_TAKE_TASK  // A/B experiment only: the single-cursor dispenser
+__device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uint32_t n_queues, uint32_t n_tasks, bool want, uint32_t& task) {
+    uint32_t* cursor = counters + kTaskCounterStride;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
-    if (m == 0ull) return false;
+    if (m == 0ull) return kTaskNone;
     const uint32_t n = (uint32_t)__builtin_popcountll(m), avail = pool.end - pool.next;
     uint32_t fresh = 0;
-    if (n > avail) {  // wave-uniform: one more chunk covers the request (n <= 64 = kTaskChunk)
+    if (n > avail) {
         const int leader = __builtin_ctzll(m);
         uint32_t v = 0;
         if ((int)(threadIdx.x & 63u) == leader) v = atomicAdd(cursor, kTaskChunk);
@@ -86,47 +94,113 @@ __device__ __forceinline__ bool take_task(TaskPool& pool, uint32_t* cursor, uint
     } else {
         pool.next += n;
     }
-    return want && task < n_tasks;
+    if (!want) return kTaskNone;
+    return task < n_tasks ? kTaskGot : kTaskExhausted;
 }
+#else
+__device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uint32_t n_queues, uint32_t n_tasks, bool want, uint32_t& task) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+    if (m == 0ull) return kTaskNone;
+    const uint32_t n = (uint32_t)__builtin_popcountll(m), avail = pool.end - pool.next;
+    uint32_t fresh = 0, fresh_n = 0;
+    if (n > avail) {  // wave-uniform: one more chunk (n <= 64 = kTaskChunk)
+        const uint32_t per = task_queue_span(n_tasks, n_queues);
+        const int leader = __builtin_ctzll(m);
+        while (pool.tried < n_queues) {
+            uint32_t v = 0;
+            if ((int)(threadIdx.x & 63u) == leader) v = atomicAdd(counters + (1u + pool.queue) * kTaskCounterStride, kTaskChunk);
+            v = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
+            const uint32_t qbeg = pool.queue * per;  // (< 2^32: launch_render bounds n_tasks)
+            if (qbeg < n_tasks) {
+                const uint32_t qlen = (n_tasks - qbeg < per) ? n_tasks - qbeg : per;
+                if (v < qlen) {
+                    fresh = qbeg + v;
+                    fresh_n = (qlen - v < kTaskChunk) ? qlen - v : kTaskChunk;
+                    break;
+                }
+            }
+            pool.queue = (pool.queue + 1u) & (n_queues - 1u);
+            pool.tried++;
+        }
+    }
+    const uint32_t rank = lane_rank(m);
+    bool got = true;
+    if (rank < avail) {
+        task = pool.next + rank;
+    } else {
+        task = fresh + (rank - avail);
+        got = rank - avail < fresh_n;
+    }
+    if (n > avail) {
+        const uint32_t used = (n - avail < fresh_n) ? n - avail : fresh_n;
+        pool.next = fresh + used;
+        pool.end = fresh + fresh_n;
+    } else {
+        pool.next += n;
+    }
+    if (!want) return kTaskNone;
+    if (got) return kTaskGot;
+    return pool.tried >= n_queues ? kTaskExhausted : kTaskNone;
+}
+#endif
 
 // Primary pass.  grid = owned tiles x 16 workgroups of 16x16 pixels.
 template <int ACCEL, bool STATS>
 __global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
+    __shared__ uint32_t s_wave_hits[4], s_list_base;
     if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
+    if (a.task_counters_next && blockIdx.x == 0 && threadIdx.x <= kTaskQueues) a.task_counters_next[threadIdx.x * kTaskCounterStride] = 0u;
     uint32_t x, y;
-    if (!lane_pixel(blockIdx.x, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
+    const bool valid = lane_pixel(blockIdx.x, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y);
     const uint32_t pixel = y * a.w + x;
     Ray r0;
-    if (a.rays) {
-        const float* p = a.rays + 6 * (size_t)pixel;
-        r0.o = mk3(p[0], p[1], p[2]);
-        r0.d = mk3(p[3], p[4], p[5]);
-    } else {
-        r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
-    }
+    r0.o = r0.d = mk3(0.0f, 0.0f, 0.0f);
     WorkCounters wc0 = {0, 0, 0};
     HitRec h0;
     h0.t = kF32Max;
     h0.idx = -1;
-    // integrator.rs:47: with bounces == 0 the loop never runs and every sample is (0, 0, 0, 1)
-    if (a.bounces != 0) h0 = trace_any<ACCEL, STATS>(a, s_sph, r0.o, r0.d, wc0);
+    if (valid) {
+        if (a.rays) {
+            const float* p = a.rays + 6 * (size_t)pixel;
+            r0.o = mk3(p[0], p[1], p[2]);
+            r0.d = mk3(p[3], p[4], p[5]);
+        } else {
+            r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
+        }
+        // integrator.rs:47: with bounces == 0 the loop never runs and every sample is (0, 0, 0, 1)
+        if (a.bounces != 0) h0 = trace_any<ACCEL, STATS>(a, s_sph, r0.o, r0.d, wc0);
+    }
+    // Places in the list of path pixels: one atomic per workgroup (all of them hit one address: a wave each would make
+    // the frame's 5 000 .. 130 000 waves queue up behind it)
     const bool hit = h0.idx >= 0;
     const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(hit);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) s_wave_hits[wave] = (uint32_t)__builtin_popcountll(hit_mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_wave_hits[0] + s_wave_hits[1] + s_wave_hits[2] + s_wave_hits[3];
+        s_list_base = total ? atomicAdd(&a.task_counters[0], total) : 0u;
+    }
+    __syncthreads();
+    if (!valid) return;
     if (hit) {
         f3 pos0, nrm0;
         hit_geometry(sphere_at<ACCEL>(a, s_sph, h0.idx), r0.o, r0.d, h0.t, pos0, nrm0);
-        const int leader = __builtin_ctzll(hit_mask);
-        uint32_t base = 0;
-        if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&a.task_counters[0], (uint32_t)__builtin_popcountll(hit_mask));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        const size_t at = (size_t)base + lane_rank(hit_mask);  // this pixel's place in the list of path pixels
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < wave; ++k) before += s_wave_hits[k];
+        const size_t at = (size_t)s_list_base + before + lane_rank(hit_mask);  // this pixel's place in the list of path pixels
         a.prim[2 * at] = make_float4(pos0.x, pos0.y, pos0.z, __builtin_bit_cast(float, pixel));
         a.prim[2 * at + 1] = make_float4(nrm0.x, nrm0.y, nrm0.z, __builtin_bit_cast(float, h0.idx));
         a.prim_disc[at] = wc0.disc;
+        if (a.fresh) {  // the tasks' sums are added to a frame that starts at zero
+            a.sum[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            a.counts[pixel] = 0u;
+        }
     } else {
-        // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89); its block sums are
-        // the same sequential adds the path lanes would make: one full block, and the shorter last one on the way
+        // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89).  Its block sums are
+        // the same sequential adds a path lane would make (one full block, and the shorter last one on the way), and they
+        // are merged right here, in block order like merge_kernel does: a sky pixel never enters the task list.
         f3 light = mk3(0.0f, 0.0f, 0.0f);
         if (a.bounces != 0) light = light + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
         const uint32_t n_full = a.spp / a.sample_block, rem = a.spp % a.sample_block;
@@ -136,17 +210,16 @@ __global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
             acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
             if (s + 1 == rem) last = acc;
         }
-        if (a.partials) {
-            const size_t npix = (size_t)a.w * a.h;
-            for (uint32_t blk = 0; blk < n_full; ++blk) a.partials[(size_t)blk * npix + pixel] = acc;
-            if (rem) a.partials[(size_t)n_full * npix + pixel] = last;  // (n_blocks = n_full + 1 then)
-        } else {  // a single block: merged right here
-            if (!n_full) acc = last;
-            float4 t = a.sum[pixel];
-            t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
-            a.sum[pixel] = t;
-            a.counts[pixel] += a.spp;
+        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t n = 0;
+        if (!a.fresh) {
+            t = a.sum[pixel];
+            n = a.counts[pixel];
         }
+        for (uint32_t blk = 0; blk < n_full; ++blk) { t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w; }
+        if (rem) { t.x += last.x; t.y += last.y; t.z += last.z; t.w += last.w; }
+        a.sum[pixel] = t;
+        a.counts[pixel] = n + a.spp;
         if (STATS) {  // algorithmic counts, as the reference would execute them: the primary ray per sample
             atomicAdd(&a.stats[0], (unsigned long long)a.spp);
             if (a.bounces != 0) {
@@ -164,8 +237,8 @@ __global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
 
 // State of the task a lane works on: a few registers; what follows from (pixel, block) is recomputed where it is needed.
 struct TaskState {
-    uint32_t pixel, blk, s;  // s = samples of the block done so far
-    float4 acc;              // the block sum
+    uint32_t pixel, task, s;  // task id = list entry x n_blocks + block; s = samples of the block done so far
+    float4 acc;               // the block sum
 };
 struct PrimaryHit {  // a path pixel's record from primary_kernel
     f3 pos, nrm;
@@ -189,12 +262,12 @@ __device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t
 // merge_kernel when the launch has several blocks.
 __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t) {
     if (a.partials) {
-        a.partials[(size_t)t.blk * ((size_t)a.w * a.h) + t.pixel] = t.acc;
-    } else {
+        a.partials[t.task] = t.acc;
+    } else {  // a single block (task id = list entry): the whole launch of this pixel
         float4 v = a.sum[t.pixel];
         v.x += t.acc.x; v.y += t.acc.y; v.z += t.acc.z; v.w += t.acc.w;
         a.sum[t.pixel] = v;
-        a.counts[t.pixel] += task_spp(a, t.blk);
+        a.counts[t.pixel] += a.spp;
     }
 }
 
@@ -205,8 +278,8 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     stage_spheres(s_sph, a.spheres, a.n_spheres);
     const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
-    uint32_t* const cursor = a.task_counters + 1;
     TaskPool pool;
+    pool.queue = blockIdx.x & (a.n_queues - 1u);
 
     // per-lane work statistics (STATS only): samples, traces, discriminant >= 0 tests, hits
     uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
@@ -226,7 +299,7 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
     const bool fast = a.fast_materials != 0;
     const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
     TaskState t;
-    t.pixel = t.blk = t.s = 0;
+    t.pixel = t.task = t.s = 0;
     t.acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     PrimaryHit p0;  // of the task's pixel; three spheres leave the registers for it
     p0.pos = p0.nrm = mk3(0.0f, 0.0f, 0.0f);
@@ -245,17 +318,22 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
         // ---- lanes without a task take the next one
         uint32_t task = 0;
         const bool want = !have && !finished;
-        if (take_task(pool, cursor, n_tasks, want, task)) {
+        const int took = take_task(pool, a.task_counters, a.n_queues, n_tasks, want, task);
+        // (a lane's three outcomes as one branch and one mask operation: a three-way branch costs the loop 40 register
+        // copies per iteration)
+        finished = finished || took == kTaskExhausted;
+        if (took == kTaskGot) {
             const uint32_t entry = task / a.n_blocks;  // task = list entry x n_blocks + block
-            t.blk = task - entry * a.n_blocks;
+            const uint32_t blk = task - entry * a.n_blocks;
+            t.task = task;
             p0 = load_primary(a, entry);
             if (STATS) p0_disc = a.prim_disc[entry];
             t.pixel = p0.pixel;
             t.s = 0;
             t.acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            t_spp = task_spp(a, t.blk);
+            t_spp = task_spp(a, blk);
             t_key = pixel_key(a.seed_lo, t.pixel);
-            t_base = a.sample_base + t.blk * a.sample_block;
+            t_base = a.sample_base + blk * a.sample_block;
             have = true;
             b = 0;
             skey = sample_key(a.seed_hi, t_key, t_base);
@@ -263,10 +341,8 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
             contrib = mk3(1.0f, 1.0f, 1.0f);
             light = mk3(0.0f, 0.0f, 0.0f);
             if (STATS) { n_traces++; n_disc += p0_disc; n_hits++; }
-        } else if (want) {
-            finished = true;
         }
-        if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;  // every lane ran out of tasks
+        if (__builtin_amdgcn_ballot_w64(have || !finished) == 0ull) break;  // every lane ran out of tasks
         if (have) {
             profile(0);
             // ---- shade the hit of bounce b (integrator.rs:50-81)
@@ -397,8 +473,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
     const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;
-    uint32_t* const cursor = a.task_counters + 1;
     TaskPool pool;
+    pool.queue = blockIdx.x & (a.n_queues - 1u);
     uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
     WorkCounters wc = {0, 0, 0};
     // lane-activity profile (STATS only; ir_get_lane_profile): rounds of the wave loop (lanes with work left), shading
@@ -458,7 +534,9 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
         if (n_wait >= kShadeBatch || n_trav == 0) {
             uint32_t task = 0;
             const bool want = waiting && !have;
-            if (take_task(pool, cursor, n_tasks, want, task)) {
+            const int took = take_task(pool, a.task_counters, a.n_queues, n_tasks, want, task);
+            finished = finished || took == kTaskExhausted;
+            if (took == kTaskGot) {
                 const uint32_t entry = task / a.n_blocks;
                 task_word(0) = entry;
                 task_word(1) = task - entry * a.n_blocks;
@@ -466,8 +544,6 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                 task_word(3) = task_word(4) = task_word(5) = task_word(6) = 0u;  // the block sum starts at +0
                 have = true;
                 restart();
-            } else if (want) {
-                finished = true;
             }
             if (waiting && have) {
                 profile(1);
@@ -507,7 +583,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                         if (done_now >= task_spp(a, blk)) {
                             TaskState t;
                             t.pixel = f32_bits(a.prim[2 * (size_t)task_word(0)].w);
-                            t.blk = blk;
+                            t.task = task_word(0) * a.n_blocks + blk;
                             t.s = done_now;
                             t.acc = acc;
                             end_task(a, t);
@@ -630,16 +706,17 @@ __global__ __launch_bounds__(256) void primary_hits_kernel(const HitsArgs a) {
 }
 
 // Accumulator::merge_tile (full_buffer.rs:107-125) for the sample blocks of one launch: framebuffer += block sum, in
-// block order; sample_counts += samples of the launch.
+// block order; sample_counts += samples of the launch.  One lane per path pixel (list entry); sky pixels were merged by
+// the primary pass.
 __global__ __launch_bounds__(256) void merge_kernel(const RenderArgs a) {
-    uint32_t x, y;
-    if (!lane_pixel(blockIdx.x, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) return;
-    const uint32_t pixel = y * a.w + x;
-    const size_t npix = (size_t)a.w * a.h;
+    const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
+    if (entry >= a.task_counters[0]) return;
+    const uint32_t pixel = f32_bits(a.prim[2 * (size_t)entry].w);
+    const float4* p = a.partials + (size_t)entry * a.n_blocks;
     float4 t = a.sum[pixel];
     for (uint32_t b = 0; b < a.n_blocks; ++b) {
-        const float4 p = a.partials[(size_t)b * npix + pixel];
-        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        const float4 v = p[b];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
     a.sum[pixel] = t;
     a.counts[pixel] += a.spp;
@@ -717,10 +794,19 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     a.n_blocks = (a.spp + a.sample_block - 1) / a.sample_block;
     if (a.n_blocks == 1) a.partials = nullptr;  // single block: the kernels merge into the accumulator themselves
     const dim3 block(256);
-    hipError_t e = hipMemsetAsync(a.task_counters, 0, 2 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (!a.task_counters_next) {  // the caller does not alternate counter pairs: zero the one pair
+        e = hipMemsetAsync(a.task_counters, 0, kTaskCounterPairStride * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
     const bool skymis = a.sky_marginal != nullptr;
     const uint64_t max_tasks = (uint64_t)a.wgs_per_layer * 256u * a.n_blocks;
+    // Queues: one address serves 100 .. 300 M atomics/s chip-wide.  Long blocks on a big frame ask rarely (C2: 10 M/s)
+    // and run 1.5 % faster on a single queue (measured on one box, tools/ab_bench.sh); short blocks or few tasks per wave
+    // (C1: every wave asks in the first microseconds, then every few iterations) need the requests spread out.
+    a.n_queues = (a.sample_block >= 64 && max_tasks >= (2ull << 20)) ? 1u : kTaskQueues;
+    static const int forced_queues = getenv("IR_DEBUG_TASK_QUEUES") ? atoi(getenv("IR_DEBUG_TASK_QUEUES")) : 0;  // tools/ only
+    if (forced_queues >= 1 && forced_queues <= (int)kTaskQueues && (forced_queues & (forced_queues - 1)) == 0) a.n_queues = (uint32_t)forced_queues;
     const void* paths = nullptr;
     size_t lds = 0;
     if (accel == kAccelLbvh) {

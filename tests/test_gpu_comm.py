@@ -122,14 +122,14 @@ def test_auto_sample_block_and_memory_bounded_blocks(tracer, oracle):
     from path_tracer_amd import _capi, workloads as W
     lib, ctx = _capi.lib, tracer._ctx
     scene = W.scene_s1()
-    # C1's shape: 800x450 = 13x8 tiles = 1664 workgroups-worth of pixels; 64 spp -> blocks of 16 (4 x 1664 >= 4096)
+    # C1's shape: 800x450 = 13x8 tiles = 1664 workgroups-worth of pixels; 64 spp -> blocks of 8 (8 x 1664 >= 8192)
     w, h, spp = 800, 450, 64
     cam = W.default_camera(w, h)
     tracer.set_active_camera(cam)
     tracer.set_sample_block(_capi.IR_SAMPLE_BLOCK_AUTO)
     sb = C.c_uint32()
     _capi.check(ctx, lib.ir_get_sample_block(ctx, w, h, spp, C.byref(sb)))
-    assert sb.value == 16
+    assert sb.value == 8
     _capi.check(ctx, lib.ir_get_sample_block(ctx, 1920, 1080, 1024, C.byref(sb)))
     assert sb.value == 128
     _capi.check(ctx, lib.ir_get_sample_block(ctx, 64, 64, 1, C.byref(sb)))
@@ -138,7 +138,7 @@ def test_auto_sample_block_and_memory_bounded_blocks(tracer, oracle):
         tracer.render(scene, w, h, False, spp=spp)
         s, c = tracer.get_radiance()
         ocam = oracle.camera_from(cam, w, h)
-        oracle.set_sample_block(16)
+        oracle.set_sample_block(8)
         want, wcnt, _, _ = oracle.render(ocam, scene, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1, threads=16)
         assert np.array_equal(s.view(np.uint32), want.view(np.uint32)) and np.array_equal(c, wcnt)
         # block of 1 at 1080p, 4096 spp
