@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
     p0.pixel = 0;
     uint32_t p0_disc = 0;  // tests with discriminant >= 0 of the primary trace (statistics only)
     uint32_t t_spp = 0, t_key = 0, t_base = 0;  // samples of the block, pixel key, first sample index of the block
-    bool have = false, finished = false;
+    bool have = false, finished = false, start = false;
     // path state
     uint32_t b = 0, skey = 0;
     f3 pos = p0.pos, nrm = p0.nrm;
@@ -335,16 +335,20 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
             t_key = pixel_key(a.seed_lo, t.pixel);
             t_base = a.sample_base + blk * a.sample_block;
             have = true;
-            b = 0;
-            skey = sample_key(a.seed_hi, t_key, t_base);
-            pos = p0.pos; nrm = p0.nrm; idx = p0.idx;
-            contrib = mk3(1.0f, 1.0f, 1.0f);
-            light = mk3(0.0f, 0.0f, 0.0f);
-            if (STATS) { n_traces++; n_disc += p0_disc; n_hits++; }
+            start = true;
         }
         if (__builtin_amdgcn_ballot_w64(have || !finished) == 0ull) break;  // every lane ran out of tasks
         if (have) {
             profile(0);
+            if (start) {  // a sample starts at the pixel's primary hit (one place for the first and the later ones)
+                start = false;
+                b = 0;
+                skey = sample_key(a.seed_hi, t_key, t_base + t.s);
+                pos = p0.pos; nrm = p0.nrm; idx = p0.idx;
+                contrib = mk3(1.0f, 1.0f, 1.0f);
+                light = mk3(0.0f, 0.0f, 0.0f);
+                if (STATS) { n_traces++; n_disc += p0_disc; n_hits++; }
+            }
             // ---- shade the hit of bounce b (integrator.rs:50-81)
             const float4 m_brdf = a.shade[2 * idx];
             const float4 m_emit = a.shade[2 * idx + 1];
@@ -431,12 +435,7 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
                     if (STATS) n_samples += t_spp;
                     have = false;
                 } else {  // regenerate at the primary hit with the next sample index
-                    b = 0;
-                    pos = p0.pos; nrm = p0.nrm; idx = p0.idx;
-                    contrib = mk3(1.0f, 1.0f, 1.0f);
-                    light = mk3(0.0f, 0.0f, 0.0f);
-                    skey = sample_key(a.seed_hi, t_key, t_base + t.s);
-                    if (STATS) { n_traces++; n_disc += p0_disc; n_hits++; }
+                    start = true;
                 }
             }
         }
