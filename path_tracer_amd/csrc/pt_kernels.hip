@@ -813,6 +813,8 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         if (stats) hipLaunchKernelGGL((primary_kernel<kAccelLbvh, true>), dim3(a.wgs_per_layer), block, lds, stream, a);
         else hipLaunchKernelGGL((primary_kernel<kAccelLbvh, false>), dim3(a.wgs_per_layer), block, lds, stream, a);
         lds += 7 * 256 * sizeof(uint32_t);  // paths_lbvh_kernel keeps each lane's task state behind the stacks
+        static const size_t tree_pad = getenv("IR_DEBUG_LDS_PAD") ? (size_t)atol(getenv("IR_DEBUG_LDS_PAD")) : 0;  // occupancy experiments (tools/)
+        lds += tree_pad;
         paths = stats ? (skymis ? (const void*)paths_lbvh_kernel<true, true> : (const void*)paths_lbvh_kernel<true, false>)
                       : (skymis ? (const void*)paths_lbvh_kernel<false, true> : (const void*)paths_lbvh_kernel<false, false>);
     } else {
