@@ -4,7 +4,7 @@
 // only PRUNES that scan: leaf tests use the scan's arithmetic, the accept rule (t > 0, smaller t wins, equal t keeps
 // the lower ORIGINAL index) reproduces "first strictly smaller in index order", and node tests are conservative
 // (boxes are inflated at traversal time by a distance-proportional pad that dominates every rounding error of the
-// sphere test), so the resulting (t, index) equals the scan's.
+// sphere test, derivation in pt_device.h), so the resulting (t, index) equals the scan's.
 #pragma once
 #include <stdint.h>
 

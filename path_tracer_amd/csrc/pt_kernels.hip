@@ -66,38 +66,15 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {  // set
 // (pt_kernels.h): atomics on ONE address are served one after the other chip-wide (measured: 3 .. 10 ns each, so the 8 192
 // first requests of a launch alone kept its last wave waiting for up to 80 us, and 4-sample blocks ran at a third of the
 // rate of 16-sample blocks).  A wave starts on the queue of its workgroup (blockIdx mod kTaskQueues), draws chunks of 64
-// ids from it and moves on to the next queue when one is exhausted; after kTaskQueues exhausted queues it is done.
+// ids from it and moves on to the next queue when one is exhausted; after n_queues exhausted queues it is done.  (Reading
+// all cursors with one load to skip exhausted queues was tried: an empty launch drops from 88 to 38 us, but C1 gets 25 %
+// slower — the loads see stale cursors and send waves to queues that are gone; tools/ab_c1.sh.)
 // `want`: this lane asks for a task.  Every lane of the wave must call it together.
 enum { kTaskNone = 0, kTaskGot = 1, kTaskExhausted = -1 };  // kTaskNone: not asked, or ask again (the chunk was short)
 struct TaskPool {
     uint32_t next = 0, end = 0;     // wave-uniform: unclaimed ids [next, end) of the wave's current chunk
     uint32_t queue = 0, tried = 0;  // current queue; queues this wave has found exhausted
 };
-#ifdef IR_OLD_TAKE_TASK  // A/B experiment only: the single-cursor dispenser
-__device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uint32_t n_queues, uint32_t n_tasks, bool want, uint32_t& task) {
-    uint32_t* cursor = counters + kTaskCounterStride;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
-    if (m == 0ull) return kTaskNone;
-    const uint32_t n = (uint32_t)__builtin_popcountll(m), avail = pool.end - pool.next;
-    uint32_t fresh = 0;
-    if (n > avail) {
-        const int leader = __builtin_ctzll(m);
-        uint32_t v = 0;
-        if ((int)(threadIdx.x & 63u) == leader) v = atomicAdd(cursor, kTaskChunk);
-        fresh = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
-    }
-    const uint32_t rank = lane_rank(m);
-    task = rank < avail ? pool.next + rank : fresh + (rank - avail);
-    if (n > avail) {
-        pool.next = fresh + (n - avail);
-        pool.end = fresh + kTaskChunk;
-    } else {
-        pool.next += n;
-    }
-    if (!want) return kTaskNone;
-    return task < n_tasks ? kTaskGot : kTaskExhausted;
-}
-#else
 __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uint32_t n_queues, uint32_t n_tasks, bool want, uint32_t& task) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
     if (m == 0ull) return kTaskNone;
@@ -142,7 +119,6 @@ __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uin
     if (got) return kTaskGot;
     return pool.tried >= n_queues ? kTaskExhausted : kTaskNone;
 }
-#endif
 
 // Primary pass.  grid = owned tiles x 16 workgroups of 16x16 pixels.
 template <int ACCEL, bool STATS>
