@@ -376,6 +376,13 @@ struct LbvhView {
 // LBVH kernel interleaves steps of different lanes' rays with shading (render_lbvh_kernel), trace_lbvh runs one to
 // the end.  The stack lives outside (LDS on the device: entry k of this lane at stack[k * stride]).
 constexpr int kCursorDone = 0x7fffffff;
+PT_DEV float box_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 struct LbvhCursor {
     f3 o, d;
     float a4, a2, ix, iy, iz;
@@ -390,9 +397,11 @@ PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
     const float a = dot(d, d);
     c.a4 = 4.0f * a;
     c.a2 = 2.0f * a;
-    c.ix = 1.0f / d.x;  // +-inf for an axis-parallel ray
-    c.iy = 1.0f / d.y;
-    c.iz = 1.0f / d.z;
+    // +-inf for an axis-parallel ray.  On the device the hardware reciprocal (1 ulp): the slab test only has to be
+    // conservative, and the pad's margin covers a few ulp of every slab distance (see above)
+    c.ix = box_rcp(d.x);
+    c.iy = box_rcp(d.y);
+    c.iz = box_rcp(d.z);
     c.best = kF32Max;
     c.idx = -1;
     c.cur = 0;
@@ -433,7 +442,7 @@ PT_DEV void cursor_inner_step(const LbvhView& v, LbvhCursor& c, int* stack, uint
     // Written with selects around ONE push and ONE pop: the four-way if/else cascade cost the divergent wave four nested
     // exec-mask regions (35 scalar instructions per step, a fifth of the step).
     const bool both = hl && hr, any = hl || hr;
-    const bool right_first = both ? (tr < tl) : hr;  // enter the right child first: it is nearer, or the only one hit
+    const bool right_first = hr && (!hl || tr < tl);  // enter the right child first: it is nearer, or the only one hit
     const int near = right_first ? rr : rl, far = right_first ? rl : rr;
     if (both) {
         stack[c.sp * stride] = far;

@@ -438,8 +438,14 @@ __global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
 // shading block only once enough lanes wait for it (or nobody is left traversing), so short rays do not sit out long
 // ones: they go on to their next ray.
 // ----------------------------------------------------------------------------------------------------
-constexpr uint32_t kShadeBatch = 32;   // run the shading block when this many lanes wait for it
-constexpr uint32_t kStepsPerRound = 8; // traversal steps between two looks at the wave's state
+#ifndef IR_SHADE_BATCH
+#define IR_SHADE_BATCH 32
+#endif
+#ifndef IR_STEPS_PER_ROUND
+#define IR_STEPS_PER_ROUND 4
+#endif
+constexpr uint32_t kShadeBatch = IR_SHADE_BATCH;         // run the shading block when this many lanes wait for it
+constexpr uint32_t kStepsPerRound = IR_STEPS_PER_ROUND;  // traversal steps between two looks at the wave's state
 
 // SKYMIS (sky importance sampling, see paths_kernel): the shadow ray is one more traversal of the lane's state machine,
 // run before the bounce ray, which waits in registers (direction, density, the strategy's weighted sky term).
@@ -630,7 +636,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
         }
         // Two node steps per leaf step: lanes that stay on inner nodes (most of them) descend two levels for every pass
         // of the divergent leaf code, which then finds more lanes waiting for it (+7 % on C3 over one-and-one; three
-        // node steps or a majority vote between the two kinds of step measured no better).
+        // node steps or a majority vote between the two kinds of step measured no better).  Four such steps between two
+        // looks at the wave's state (8 was right while lanes owned pixels; with tasks, refilling sooner is +3 %).
         for (uint32_t k = 0; k < kStepsPerRound; ++k) {
             if (traversing) {
                 if (cur.cur >= 0) { profile(2); cursor_inner_step<STATS>(a.bvh, cur, stack, 256u, wc.nodes); }
