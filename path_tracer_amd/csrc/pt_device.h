@@ -351,19 +351,20 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
 // hit child is entered first and the farther one is pushed on a small per-lane stack, so that `best` shrinks early
 // and prunes the far field.  Leaf tests are the scan's arithmetic; the accept rule adds "equal t keeps the lower
 // original index", which is what a scan in index order with a strict '<' returns, so the result does not depend on
-// the visiting order.  Node tests are conservative: each box is inflated by pad = (L1 distance from the ray origin to
-// the farthest box corner) * 2^-9 before the slab test.  Why that is enough (u = 2^-24, M = max(|oc|, r), a = d.d):
+// the visiting order.  Node tests are conservative: each box is inflated by pad = (max-norm distance from the ray origin
+// to the farthest box corner) * 0.003 before the slab test.  Why that is enough (u = 2^-24, M = max(|oc|, r), a = d.d):
 //   * oc = o - c is one rounding per component, i.e. the exact difference to a centre moved by <= u |oc|;
 //   * b = 2 dot(d, oc) carries <= 6u |d||oc|, cc = dot(oc, oc) - r*r <= 4u M^2, a <= 3u a; so the computed discriminant
 //     is within E <= 68 u a M^2 of D = 4a (r^2 - rho^2), rho = distance of the centre from the ray's line;
 //   * an accepted sphere has a computed t with disc >= 0; the point P = o + t d then satisfies
 //     |P - c|^2 = rho^2 + a (t - t0)^2 <= r^2 + (E + 2 sqrt(disc) |e_b| + e_b^2)/(4a) + (roundings of t and of 2a)
 //                                   <= r^2 + 45 u M^2,   so   |P - c| <= r + sqrt(45 u) M = r + 1.64e-3 M;
-//   * the box holds c +- r (built one ulp outwards), M <= the L1 distance to its farthest corner (for an origin inside the
-//     sphere that distance is >= 3r), and 2^-9 = 1.95e-3 > 1.64e-3 with room for the slab test's own roundings (a few u
-//     of |oc|): P lies inside the padded box, hence tmin <= t <= tmax, tmax > 0, and tmin <= t <= best whenever the sphere
-//     could still win.  No sphere the scan would accept with t <= best is ever pruned.
-// (2^-7 was used until round 2; the tighter pad visits 9 % fewer nodes and 15 % fewer leaf spheres on the 10k scene.)
+//   * the box holds c +- r (built one ulp outwards), so with L = the max-norm distance from the origin to its farthest
+//     corner: |oc| <= sqrt(3) L, r <= L, M <= sqrt(3) L, and the slack is <= 1.64e-3 * sqrt(3) L = 2.84e-3 L < 0.003 L with
+//     room for the slab test's own roundings (subtraction, hardware reciprocal, product: < 5u = 3e-7 of a slab
+//     distance, against a margin of 1.6e-4 L): P lies inside the padded box, hence tmin <= t <= tmax, tmax > 0, and
+//     tmin <= t <= best whenever the sphere could still win.  No sphere the scan would accept with t <= best is pruned.
+// (Until round 2 the pad was 2^-7 of the L1 distance: 10 % more node visits and 17 % more leaf tests on the 10k scene.)
 // ----------------------------------------------------------------------------------------------------
 struct LbvhView {
     const float4* __restrict__ wide;          // 4 x float4 per inner node (lbvh.h WideNode)
@@ -408,14 +409,14 @@ PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
     c.sp = 0;
 }
 #ifndef IR_BOX_PAD
-#define IR_BOX_PAD 0.001953125f  // 2^-9; other values only in tools/ experiments (they void the parity guarantee)
+#define IR_BOX_PAD 0.003f  // other values only in tools/ experiments (they void the parity guarantee)
 #endif
 constexpr float kBoxPad = IR_BOX_PAD;
 PT_DEV bool padded_box_hit(const LbvhCursor& c, float4 lo, float4 hi, float& tmin) {
     const float lx = lo.x - c.o.x, ly = lo.y - c.o.y, lz = lo.z - c.o.z;
     const float hx = hi.x - c.o.x, hy = hi.y - c.o.y, hz = hi.z - c.o.z;
-    const float pad = (__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)) + __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy)) +
-                       __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * kBoxPad;
+    const float pad = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)), __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy))),
+                                      __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * kBoxPad;
     const float t1x = (lx - pad) * c.ix, t2x = (hx + pad) * c.ix;
     const float t1y = (ly - pad) * c.iy, t2y = (hy + pad) * c.iy;
     const float t1z = (lz - pad) * c.iz, t2z = (hz + pad) * c.iz;
