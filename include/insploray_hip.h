@@ -91,8 +91,8 @@ int ir_set_sky_filter(ir_context* ctx, int filter);
  * extension for sun-dominated skies (workload C5): at every hit whose bounce ray is traced, a second direction is drawn
  * from the sky image's own distribution (luminance x solid angle), traced as a shadow ray, and the two strategies are
  * combined with the balance heuristic.  Same expectation as the reference's estimator, far lower
- * variance; costs one more trace per bounce.  Needs a skybox (with a constant sky colour it changes nothing);
- * regeneration schedule only (both closest-hit structures), with IR_SCHEDULE_WAVEFRONT ir_render fails with IR_ESTATE. */
+ * variance; costs one more trace per bounce.  Needs a skybox (with a constant sky colour it changes nothing).  Both
+ * schedules and both closest-hit structures implement it with the same draws and sums. */
 int ir_set_sky_sampling(ir_context* ctx, int mode);
 /* Closest-hit structure: IR_ACCEL_LINEAR = the reference's linear scan (integrator.rs:106-127) over an
  * LDS-staged SoA buffer (at most 10 000 spheres); IR_ACCEL_LBVH = linear BVH over the spheres whose (t, index)

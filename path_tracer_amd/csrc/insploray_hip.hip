@@ -567,7 +567,7 @@ int prepare_scene(ir_context* ctx) {
     IR_TRY(ensure(ctx, ctx->d_spheres, 16));
     IR_TRY(ensure_bvh(ctx));
     const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
-    if (skymis && ctx->schedule != IR_SCHEDULE_WAVEFRONT) IR_TRY(ensure_sky_tables(ctx));
+    if (skymis) IR_TRY(ensure_sky_tables(ctx));
     return IR_OK;
 }
 bool scene_is_prepared(const ir_context* ctx) {
@@ -628,8 +628,6 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     const int accel = selected_accel(ctx);
     // sky importance sampling needs a sky image; with a constant sky colour there is nothing to importance-sample
     const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
-    if (skymis && ctx->schedule == IR_SCHEDULE_WAVEFRONT)
-        return fail(ctx, IR_ESTATE, "ir_render: IR_SKY_SAMPLING_MIS is implemented for the regeneration schedule only");
 
     pt::RenderArgs a;
     memset(&a, 0, sizeof(a));

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void wf_primary(const WfArgs a) {
 }
 
 // FIRST: bounce 0, paths = (sample j of the batch, owned pixel) read off the per-pixel record; else paths = a.qin.
-template <int ACCEL, bool FIRST>
+// SKYMIS: sky importance sampling (pt_kernels.hip paths_kernel): the same shadow ray, draws and weights.
+template <int ACCEL, bool FIRST, bool SKYMIS>
 __global__ __launch_bounds__(256) void wf_bounce(const WfArgs a) {
     extern __shared__ float4 s_dyn[];
     __shared__ uint32_t s_cnt[2];
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void wf_bounce(const WfArgs a) {
     const size_t npix = (size_t)a.r.w * a.r.h;
     const uint32_t B = a.r.bounces, R = a.r.rr_start, b = a.depth;
     const bool fast = a.r.fast_materials != 0;
+    const SkyTables sky_tables = {a.r.sky_marginal, a.r.sky_cond, a.r.sky_pdf, a.r.sky_marginal_guide, a.r.sky_cond_guide};
     const uint32_t owned = owned_tiles(a.r.n_tiles, a.r.tile_rank, a.r.tile_world);
     const uint32_t pixel_wgs = owned * kBlocksPerTile;  // 256-pixel groups of the owned tiles
     uint32_t count;
@@ -189,11 +191,44 @@ __global__ __launch_bounds__(256) void wf_bounce(const WfArgs a) {
             }
             if (!done && b + 1 < B) {
                 const f3 o = p.pos + p.nrm * kEps;
+                float ray_density = 0.0f;
+                if constexpr (SKYMIS) {  // the second strategy: a direction from the sky's distribution, as a shadow ray
+                    ray_density = bsdf_density_r(sqrt_cr(r2));
+                    uint32_t ix, iy;
+                    f3 ws;
+                    float sin_polar;
+                    sky_sample(sky_tables, a.r.sky_w, a.r.sky_h, draw(skey, kSkyDrawBase + 2 * b), draw(skey, kSkyDrawBase + 2 * b + 1),
+                               ix, iy, ws, sin_polar);
+                    const float c = dot(ws, p.nrm);
+                    if (c > 0.0f && sin_polar > 0.0f) {
+                        const size_t texel = (size_t)iy * a.r.sky_w + ix;
+                        const float pe = sky_density(sky_tables, texel, sin_polar);
+                        const float pa = bsdf_density_dir(c);
+                        const float wgt = pa / (pe + pa);
+                        const HitRec hs = wf_trace<ACCEL>(a, s_dyn, o, ws);
+                        if (hs.idx < 0) {
+                            f3 sk;
+                            if (a.r.sky_filter == 1) {
+                                sk = sky_bilinear(a.r.skybox, a.r.sky_w, a.r.sky_h, ws);
+                            } else {
+                                const float4 tx = a.r.skybox[texel];
+                                sk = mk3(tx.x, tx.y, tx.z);
+                            }
+                            p.light = p.light + (sk * p.contrib) * wgt;
+                        }
+                    }
+                }
                 const HitRec h = wf_trace<ACCEL>(a, s_dyn, o, wi);
                 if (h.idx >= 0) {
                     hit_geometry(wf_sphere<ACCEL>(a, s_dyn, h.idx), o, wi, h.t, p.pos, p.nrm);
                     p.idx = h.idx;
                     survives = true;
+                } else if constexpr (SKYMIS) {
+                    size_t texel;
+                    float sin_polar;
+                    const f3 sk = sky_lookup_mis(a.r.skybox, a.r.sky_w, a.r.sky_h, a.r.sky_filter, wi, texel, sin_polar);
+                    const float pe = sky_density(sky_tables, texel, sin_polar);
+                    p.light = p.light + (sk * p.contrib) * (ray_density / (ray_density + pe));
                 } else {
                     p.light = p.light + sky_eval(a.r, wi) * p.contrib;
                 }
@@ -226,14 +261,17 @@ __device__ __forceinline__ void store_path(const WfQueue& q, uint32_t i, const P
     q.f[9 * c + i] = p.light.x; q.f[10 * c + i] = p.light.y; q.f[11 * c + i] = p.light.z;
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(256, 6) void wf_bounce_tree(const WfArgs a) {
+// SKYMIS: the shadow ray of the sky strategy is one more traversal of the lane's state machine, run before the bounce
+// ray, which waits in registers (as in paths_lbvh_kernel).
+template <bool FIRST, bool SKYMIS>
+__global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void wf_bounce_tree(const WfArgs a) {
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const size_t npix = (size_t)a.r.w * a.r.h;
     const uint32_t B = a.r.bounces, R = a.r.rr_start, b = a.depth;
     const bool fast = a.r.fast_materials != 0;
+    const SkyTables sky_tables = {a.r.sky_marginal, a.r.sky_cond, a.r.sky_pdf, a.r.sky_marginal_guide, a.r.sky_cond_guide};
     const uint32_t pixel_wgs = owned_tiles(a.r.n_tiles, a.r.tile_rank, a.r.tile_world) * kBlocksPerTile;
     uint32_t count;
     if constexpr (FIRST) {
@@ -254,6 +292,10 @@ __global__ __launch_bounds__(256, 6) void wf_bounce_tree(const WfArgs a) {
     bool busy = false;        // the lane holds a path
     bool fresh = false;       // ... that has not been shaded yet
     bool traversing = false;  // ... whose bounce ray is still in the tree
+    // SKYMIS only: cur is the shadow ray; the bounce ray (same origin, wi_next) follows it
+    bool shadow = false;
+    f3 wi_next = mk3(0, 0, 0), sky_term = mk3(0, 0, 0);
+    float ray_density = 0.0f;
 
     for (;;) {
         // ---- hand input entries to the idle lanes
@@ -321,16 +363,31 @@ __global__ __launch_bounds__(256, 6) void wf_bounce_tree(const WfArgs a) {
         if (n_wait >= 32u || n_inner + n_leaf == 0) {
             bool survives = false;
             if (waiting) {
-                if (!fresh) {  // the bounce ray has landed (integrator.rs:50-51, 82-90)
-                    if (cur.idx >= 0) {
-                        hit_geometry(a.r.spheres[cur.idx], cur.o, cur.d, cur.best, p.pos, p.nrm);
-                        p.idx = cur.idx;
-                        survives = true;
+                if (!fresh) {  // a ray has landed (integrator.rs:50-51, 82-90)
+                    if (SKYMIS && shadow) {
+                        if (cur.idx < 0) p.light = p.light + sky_term;
+                        shadow = false;
+                        cursor_begin(cur, cur.o, wi_next);  // the bounce ray leaves the same point as the shadow ray
+                        traversing = true;
                     } else {
-                        p.light = p.light + sky_eval(a.r, cur.d) * p.contrib;
-                        a.values[(size_t)p.smp * npix + p.pix] = make_float4(p.light.x, p.light.y, p.light.z, 0.0f);
+                        if (cur.idx >= 0) {
+                            hit_geometry(a.r.spheres[cur.idx], cur.o, cur.d, cur.best, p.pos, p.nrm);
+                            p.idx = cur.idx;
+                            survives = true;
+                        } else {
+                            if constexpr (SKYMIS) {
+                                size_t texel;
+                                float sin_polar;
+                                const f3 sk = sky_lookup_mis(a.r.skybox, a.r.sky_w, a.r.sky_h, a.r.sky_filter, cur.d, texel, sin_polar);
+                                const float pe = sky_density(sky_tables, texel, sin_polar);
+                                p.light = p.light + (sk * p.contrib) * (ray_density / (ray_density + pe));
+                            } else {
+                                p.light = p.light + sky_eval(a.r, cur.d) * p.contrib;
+                            }
+                            a.values[(size_t)p.smp * npix + p.pix] = make_float4(p.light.x, p.light.y, p.light.z, 0.0f);
+                        }
+                        busy = false;
                     }
-                    busy = false;
                 } else {  // shade the hit of bounce b (integrator.rs:50-81)
                     fresh = false;
                     const uint32_t skey = sample_key(a.r.seed_hi, pixel_key(a.r.seed_lo, p.pix), a.r.sample_base + a.batch_first + p.smp);
@@ -352,7 +409,35 @@ __global__ __launch_bounds__(256, 6) void wf_bounce_tree(const WfArgs a) {
                         }
                     }
                     if (!done && b + 1 < B) {
-                        cursor_begin(cur, p.pos + p.nrm * kEps, wi);
+                        const f3 o = p.pos + p.nrm * kEps;
+                        bool shadow_first = false;
+                        if constexpr (SKYMIS) {
+                            ray_density = bsdf_density_r(sqrt_cr(r2));
+                            uint32_t ix, iy;
+                            f3 ws;
+                            float sin_polar;
+                            sky_sample(sky_tables, a.r.sky_w, a.r.sky_h, draw(skey, kSkyDrawBase + 2 * b), draw(skey, kSkyDrawBase + 2 * b + 1),
+                                       ix, iy, ws, sin_polar);
+                            const float c = dot(ws, p.nrm);
+                            if (c > 0.0f && sin_polar > 0.0f) {
+                                const size_t texel = (size_t)iy * a.r.sky_w + ix;
+                                const float pe = sky_density(sky_tables, texel, sin_polar);
+                                const float pa = bsdf_density_dir(c);
+                                f3 sk;
+                                if (a.r.sky_filter == 1) {
+                                    sk = sky_bilinear(a.r.skybox, a.r.sky_w, a.r.sky_h, ws);
+                                } else {
+                                    const float4 tx = a.r.skybox[texel];
+                                    sk = mk3(tx.x, tx.y, tx.z);
+                                }
+                                sky_term = (sk * p.contrib) * (pa / (pe + pa));
+                                wi_next = wi;
+                                shadow = true;
+                                shadow_first = true;
+                                cursor_begin(cur, o, ws);
+                            }
+                        }
+                        if (!shadow_first) cursor_begin(cur, o, wi);
                         traversing = true;
                     } else {  // roulette / bounce budget: no sky term (integrator.rs:47,74,92)
                         a.values[(size_t)p.smp * npix + p.pix] = make_float4(p.light.x, p.light.y, p.light.z, 0.0f);
@@ -442,9 +527,13 @@ hipError_t init_wavefront_kernels() {
     const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
     hipError_t e = hipFuncSetAttribute((const void*)wf_primary<kAccelLinear>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)wf_bounce<kAccelLinear, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)wf_bounce<kAccelLinear, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    const void* scans[] = {(const void*)wf_bounce<kAccelLinear, true, false>, (const void*)wf_bounce<kAccelLinear, false, false>,
+                           (const void*)wf_bounce<kAccelLinear, true, true>, (const void*)wf_bounce<kAccelLinear, false, true>};
+    for (const void* f : scans) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // Renders a.r.spp samples per owned pixel (sample indices a.r.sample_base ...) into a.r.sum / a.r.counts.
@@ -457,6 +546,7 @@ hipError_t launch_wavefront(const WfArgs& a_in, int accel, uint32_t per_batch, u
     if (per_batch == 0 || wavefront_queue_slots((size_t)owned * kTile * kTile * per_batch, bounce_wgs) > a.qin.cap)
         return hipErrorInvalidValue;  // the host sizes the queues with wavefront_queue_slots
     const size_t lds = accel == kAccelLbvh ? (size_t)a.r.bvh.stack_depth * 256 * sizeof(int) : (size_t)a.r.n_spheres * sizeof(float4);
+    const bool skymis = a.r.sky_marginal != nullptr;  // sky importance sampling tables present (pt_kernels.h)
     hipError_t e;
 
     if (accel == kAccelLbvh) {
@@ -488,16 +578,20 @@ hipError_t launch_wavefront(const WfArgs& a_in, int accel, uint32_t per_batch, u
                 if ((e = hipMemsetAsync(q1.count, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
                 if (accel == kAccelLbvh) {
                     if ((e = hipMemsetAsync(a.in_cursor, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-                    if (d == 0) {
-                        hipLaunchKernelGGL((wf_bounce_tree<true>), dim3(bounce_wgs), block, lds, stream, a);
+                    if (skymis) {
+                        if (d == 0) hipLaunchKernelGGL((wf_bounce_tree<true, true>), dim3(bounce_wgs), block, lds, stream, a);
+                        else hipLaunchKernelGGL((wf_bounce_tree<false, true>), dim3(bounce_wgs), block, lds, stream, a);
                     } else {
-                        hipLaunchKernelGGL((wf_bounce_tree<false>), dim3(bounce_wgs), block, lds, stream, a);
+                        if (d == 0) hipLaunchKernelGGL((wf_bounce_tree<true, false>), dim3(bounce_wgs), block, lds, stream, a);
+                        else hipLaunchKernelGGL((wf_bounce_tree<false, false>), dim3(bounce_wgs), block, lds, stream, a);
                     }
                 } else {
-                    if (d == 0) {
-                        hipLaunchKernelGGL((wf_bounce<kAccelLinear, true>), dim3(bounce_wgs), block, lds, stream, a);
+                    if (skymis) {
+                        if (d == 0) hipLaunchKernelGGL((wf_bounce<kAccelLinear, true, true>), dim3(bounce_wgs), block, lds, stream, a);
+                        else hipLaunchKernelGGL((wf_bounce<kAccelLinear, false, true>), dim3(bounce_wgs), block, lds, stream, a);
                     } else {
-                        hipLaunchKernelGGL((wf_bounce<kAccelLinear, false>), dim3(bounce_wgs), block, lds, stream, a);
+                        if (d == 0) hipLaunchKernelGGL((wf_bounce<kAccelLinear, true, false>), dim3(bounce_wgs), block, lds, stream, a);
+                        else hipLaunchKernelGGL((wf_bounce<kAccelLinear, false, false>), dim3(bounce_wgs), block, lds, stream, a);
                     }
                 }
                 if ((e = hipGetLastError()) != hipSuccess) return e;

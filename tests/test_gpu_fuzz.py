@@ -68,8 +68,6 @@ def _random_case(rng, large=False):
                seed=int(rng.integers(0, 2 ** 63)), accel=str(rng.choice(["auto", "linear", "lbvh"])),
                build=str(rng.choice(["host", "device", "refit"])), schedule=str(rng.choice(["regeneration", "wavefront"])),
                bilinear=bool(rng.integers(0, 2)) and sky is not None, mis=bool(rng.integers(0, 2)))
-    if cfg["schedule"] == "wavefront":
-        cfg["mis"] = False  # not implemented together (IR_ESTATE), tested elsewhere
     return scene, cam, w, h, cfg
 
 

@@ -178,14 +178,7 @@ def test_constant_sky_unchanged_and_unsupported_combinations(pta, mis, oracle):
     b, _ = mis.get_radiance()
     assert a.tobytes() == b.tobytes()
     mis.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS)
-    # wavefront schedule: reported, not silently rendered with another estimator
     sky_scene = W.scene_s1()
-    mis.set_schedule(_capi.IR_SCHEDULE_WAVEFRONT)
-    try:
-        with pytest.raises(pta.InsplorayError):
-            mis.render(sky_scene, w, h, False, spp=spp)
-    finally:
-        mis.set_schedule(_capi.IR_SCHEDULE_AUTO)
     with pytest.raises(pta.InsplorayError):
         mis.set_sky_sampling(7)
     # replacing the sky image rebuilds the tables
@@ -196,3 +189,38 @@ def test_constant_sky_unchanged_and_unsupported_combinations(pta, mis, oracle):
     s, c = mis.get_radiance()
     os_, oc, _, _ = oracle.render(oracle.camera_from(cam, w, h), other, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1)
     assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)) and not np.array_equal(s, first)
+
+
+@pytest.mark.parametrize("accel", ["scan", "lbvh"])
+@pytest.mark.parametrize("bilinear", [False, True])
+def test_wavefront_schedule_same_bits(pta, mis, oracle, accel, bilinear):
+    """The sky strategy in the wavefront schedule (shadow ray inside the bounce stages): same accumulator bits as the
+    regeneration kernels and the oracle, scan and tree, several batches per block and several blocks."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = 96, 54, 24
+    scene = W.scene_s1(skybox=_sun_sky(), emitter=False)
+    cam = W.default_camera(w, h)
+    mis.set_active_camera(cam)
+    mis.set_integrator(bounces=6, max_compulsory_bounces=2, seed=SEED)
+    mis.set_accel(_capi.IR_ACCEL_LBVH if accel == "lbvh" else _capi.IR_ACCEL_LINEAR)
+    mis.set_sky_filter(_capi.IR_SKY_BILINEAR if bilinear else _capi.IR_SKY_NEAREST)
+    oracle.set_sky_filter(1 if bilinear else 0)
+    mis.set_sample_block(16)
+    oracle.set_sample_block(16)
+    try:
+        out = {}
+        for name, sched, paths in (("wavefront", _capi.IR_SCHEDULE_WAVEFRONT, 65536), ("regeneration", _capi.IR_SCHEDULE_REGENERATION, 0)):  # wavefront first: it must build the sky tables itself
+            mis.set_schedule(sched, paths)
+            mis.render(scene, w, h, False, spp=spp)
+            out[name] = mis.get_radiance()
+        assert out["wavefront"][0].tobytes() == out["regeneration"][0].tobytes()
+        assert out["wavefront"][1].tobytes() == out["regeneration"][1].tobytes()
+        os_, oc, _, _ = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=6, rr_start=2, seed=SEED, math_mode=1)
+        assert np.array_equal(out["wavefront"][0].view(np.uint32), os_.view(np.uint32)) and np.array_equal(out["wavefront"][1], oc)
+    finally:
+        mis.set_schedule(_capi.IR_SCHEDULE_AUTO)
+        mis.set_accel(_capi.IR_ACCEL_AUTO)
+        mis.set_sky_filter(_capi.IR_SKY_NEAREST)
+        oracle.set_sky_filter(0)
+        mis.set_sample_block(128)
+        oracle.set_sample_block(128)
