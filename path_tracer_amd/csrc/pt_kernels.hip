@@ -249,8 +249,10 @@ __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t
 
 // SKYMIS: sky importance sampling (IR_SKY_SAMPLING_MIS, pt_device.h): one more direction per traced bounce, drawn from
 // the sky's distribution and traced as a shadow ray; both strategies weighted with the balance heuristic.
-template <bool STATS, bool SKYMIS>
-__global__ __launch_bounds__(256) void paths_kernel(const RenderArgs a) {
+// WG: threads per workgroup.  256 everywhere, except that a scene whose spheres fill most of a CU's LDS (thousands of
+// spheres: one workgroup per CU) runs workgroups of 1024 threads, so that 16 waves share the one staged copy instead of 4.
+template <bool STATS, bool SKYMIS, int WG = 256>
+__global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     stage_spheres(s_sph, a.spheres, a.n_spheres);
     const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
@@ -738,6 +740,7 @@ hipError_t init_kernels() {
     const int max_lds = (int)(kMaxLdsSpheres * sizeof(float4));
     const void* big_lds[] = {(const void*)paths_kernel<false, false>,          (const void*)paths_kernel<true, false>,
                              (const void*)paths_kernel<false, true>,           (const void*)paths_kernel<true, true>,
+                             (const void*)paths_kernel<false, false, 1024>,    (const void*)paths_kernel<true, false, 1024>,
                              (const void*)primary_kernel<kAccelLinear, false>, (const void*)primary_kernel<kAccelLinear, true>,
                              (const void*)primary_hits_kernel<kAccelLinear>};
     for (const void* f : big_lds) {
@@ -749,18 +752,20 @@ hipError_t init_kernels() {
 
 namespace {
 
+constexpr size_t kBigWorkgroupFromLdsBytes = 40 * 1024;
+
 // Workgroups of a persistent launch: what the device can hold at once (CUs x resident workgroups per CU for this kernel
 // and LDS size), never more than the tasks can occupy.  A workgroup too many only queues and finds the task list empty.
-hipError_t persistent_grid(const void* kernel, size_t lds, uint64_t max_tasks, uint32_t* out) {
+hipError_t persistent_grid(const void* kernel, uint32_t threads, size_t lds, uint64_t max_tasks, uint32_t* out) {
     int dev = 0, cus = 0, per_cu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds);
     if (e != hipSuccess) return e;
     if (cus < 1) cus = 1;
     if (per_cu < 1) per_cu = 1;
     uint64_t wgs = (uint64_t)cus * (uint64_t)per_cu;
-    const uint64_t useful = (max_tasks + 255) / 256;
+    const uint64_t useful = (max_tasks + threads - 1) / threads;
     if (wgs > useful) wgs = useful;
     *out = (uint32_t)(wgs < 1 ? 1 : wgs);
     return hipSuccess;
@@ -790,6 +795,7 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     static const int forced_queues = getenv("IR_DEBUG_TASK_QUEUES") ? atoi(getenv("IR_DEBUG_TASK_QUEUES")) : 0;  // tools/ only
     if (forced_queues >= 1 && forced_queues <= (int)kTaskQueues && (forced_queues & (forced_queues - 1)) == 0) a.n_queues = (uint32_t)forced_queues;
     const void* paths = nullptr;
+    uint32_t path_threads = 256;
     size_t lds = 0;
     if (accel == kAccelLbvh) {
         lds = (size_t)a.bvh.stack_depth * 256 * sizeof(int);
@@ -809,15 +815,20 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         else hipLaunchKernelGGL((primary_kernel<kAccelLinear, false>), dim3(a.wgs_per_layer), block, lds, stream, a);
         paths = stats ? (skymis ? (const void*)paths_kernel<true, true> : (const void*)paths_kernel<true, false>)
                       : (skymis ? (const void*)paths_kernel<false, true> : (const void*)paths_kernel<false, false>);
+        // more than 40 KB of spheres: fewer than four 256-thread workgroups fit a CU; let 16 waves share one staged copy
+        if (lds > kBigWorkgroupFromLdsBytes && !skymis) {
+            paths = stats ? (const void*)paths_kernel<true, false, 1024> : (const void*)paths_kernel<false, false, 1024>;
+            path_threads = 1024;
+        }
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     uint32_t grid = 1;
-    e = persistent_grid(paths, lds, max_tasks, &grid);
+    e = persistent_grid(paths, path_threads, lds, max_tasks, &grid);
     if (e != hipSuccess) return e;
     void* params[] = {(void*)&a};
     if (paths_begin && (e = hipEventRecord(paths_begin, stream)) != hipSuccess) return e;
-    e = hipLaunchKernel(paths, dim3(grid), block, params, lds, stream);
+    e = hipLaunchKernel(paths, dim3(grid), dim3(path_threads), params, lds, stream);
     if (e != hipSuccess) return e;
     if (paths_end && (e = hipEventRecord(paths_end, stream)) != hipSuccess) return e;
     if (a.n_blocks > 1) {
