@@ -388,7 +388,7 @@ struct LbvhCursor {
     f3 o, d;
     float a4, a2, ix, iy, iz;
     float best;
-    int idx;
+    int idx;       // winner so far as a LEAF-ORDER position (-1: none); cursor_hit_index() translates it at the end
     int cur;       // >= 0: inner node, < 0: leaf -(first * 8 + count) - 1, kCursorDone: finished
     uint32_t sp;   // stack entries in use
 };
@@ -472,14 +472,19 @@ PT_DEV void cursor_leaf_step(const LbvhView& v, LbvhCursor& c, const int* stack,
         if (!(b < 0.0f)) continue;
         float sq = sqrt_cr(disc);
         float t = (-b - sq) / c.a2;
-        const int orig = v.leaf_index[first + k];
-        if (t > 0.0f && (t < c.best || (t == c.best && orig < c.idx))) {
-            c.idx = orig;
+        // The winner is kept as its leaf-order position: the original index (one more dependent load) is only needed to
+        // break an exact tie, and once per ray at the end (cursor_hit_index).
+        bool better = t < c.best;
+        if (t == c.best && c.idx >= 0) better = v.leaf_index[first + k] < v.leaf_index[c.idx];
+        if (t > 0.0f && better) {
+            c.idx = (int)(first + k);
             c.best = t;
         }
     }
     c.cur = cursor_pop(c, stack, stride);
 }
+// Original sphere index of a finished traversal's winner (-1: the ray escaped)
+PT_DEV int cursor_hit_index(const LbvhView& v, const LbvhCursor& c) { return c.idx >= 0 ? v.leaf_index[c.idx] : -1; }
 // one step of a traversal run on its own: the inner node and, if that leads to a leaf, the leaf
 template <bool STATS>
 PT_DEV void cursor_step(const LbvhView& v, LbvhCursor& c, int* stack, uint32_t stride, uint32_t& disc_pos, uint32_t& node_visits,
@@ -496,7 +501,7 @@ PT_DEV HitRec trace_lbvh(const LbvhView& v, int* stack, uint32_t stride, f3 o, f
     while (c.cur != kCursorDone) cursor_step<STATS>(v, c, stack, stride, disc_pos, node_visits, leaf_tests);
     HitRec h;
     h.t = c.best;
-    h.idx = c.idx;
+    h.idx = cursor_hit_index(v, c);
     return h;
 }
 

@@ -541,8 +541,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                     } else if (cur.idx >= 0) {
                         if (STATS) n_hits++;
                         f3 pos;
-                        hit_geometry(a.spheres[cur.idx], cur.o, cur.d, cur.best, pos, nrm);
-                        idx = cur.idx;
+                        idx = cursor_hit_index(a.bvh, cur);
+                        hit_geometry(a.spheres[idx], cur.o, cur.d, cur.best, pos, nrm);
                         cur.o = pos + nrm * kEps;
                     } else {
                         if constexpr (SKYMIS) {

@@ -371,8 +371,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void wf_bounce_tree(const WfAr
                         traversing = true;
                     } else {
                         if (cur.idx >= 0) {
-                            hit_geometry(a.r.spheres[cur.idx], cur.o, cur.d, cur.best, p.pos, p.nrm);
-                            p.idx = cur.idx;
+                            p.idx = cursor_hit_index(a.r.bvh, cur);
+                            hit_geometry(a.r.spheres[p.idx], cur.o, cur.d, cur.best, p.pos, p.nrm);
                             survives = true;
                         } else {
                             if constexpr (SKYMIS) {
