@@ -75,7 +75,8 @@ struct TaskPool {
     uint32_t next = 0, end = 0;     // wave-uniform: unclaimed ids [next, end) of the wave's current chunk
     uint32_t queue = 0, tried = 0;  // current queue; queues this wave has found exhausted
 };
-__device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uint32_t n_queues, uint32_t n_tasks, bool want, uint32_t& task) {
+__device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uint32_t* s_exhausted, uint32_t n_queues, uint32_t n_tasks, bool want,
+                                         uint32_t& task) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
     if (m == 0ull) return kTaskNone;
     const uint32_t n = (uint32_t)__builtin_popcountll(m), avail = pool.end - pool.next;
@@ -84,6 +85,17 @@ __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uin
         const uint32_t per = task_queue_span(n_tasks, n_queues);
         const int leader = __builtin_ctzll(m);
         while (pool.tried < n_queues) {
+            // What the workgroup's other waves already found out saves the failing atomic: at the end of a launch every
+            // wave probes every queue once, 7 168 atomics per address at ~12 ns each (86 us for a launch without tasks);
+            // with the bits shared in LDS it is one probe per workgroup.
+            const uint32_t known = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)s_exhausted);
+            // (a queue without ids — a launch smaller than the queues — needs no probe either.  One word in memory for
+            // what OTHER workgroups found was tried too: its atomics serialise like the cursors', C1 +50 % time.)
+            if (((known >> pool.queue) & 1u) || pool.queue * per >= n_tasks) {
+                pool.queue = (pool.queue + 1u) & (n_queues - 1u);
+                pool.tried++;
+                continue;
+            }
             uint32_t v = 0;
             if ((int)(threadIdx.x & 63u) == leader) v = atomicAdd(counters + (1u + pool.queue) * kTaskCounterStride, kTaskChunk);
             v = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
@@ -96,6 +108,7 @@ __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uin
                     break;
                 }
             }
+            if ((int)(threadIdx.x & 63u) == leader) atomicOr(s_exhausted, 1u << pool.queue);
             pool.queue = (pool.queue + 1u) & (n_queues - 1u);
             pool.tried++;
         }
@@ -254,7 +267,9 @@ __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t
 template <bool STATS, bool SKYMIS, int WG = 256>
 __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
-    stage_spheres(s_sph, a.spheres, a.n_spheres);
+    __shared__ uint32_t s_exhausted;  // bit q: a wave of this workgroup found task queue q exhausted
+    if (threadIdx.x == 0) s_exhausted = 0u;
+    stage_spheres(s_sph, a.spheres, a.n_spheres);  // (ends with the barrier that publishes s_exhausted too)
     const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
     TaskPool pool;
     pool.queue = blockIdx.x & (a.n_queues - 1u);
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
         // ---- lanes without a task take the next one
         uint32_t task = 0;
         const bool want = !have && !finished;
-        const int took = take_task(pool, a.task_counters, a.n_queues, n_tasks, want, task);
+        const int took = take_task(pool, a.task_counters, &s_exhausted, a.n_queues, n_tasks, want, task);
         // (a lane's three outcomes as one branch and one mask operation: a three-way branch costs the loop 40 register
         // copies per iteration)
         finished = finished || took == kTaskExhausted;
@@ -455,6 +470,9 @@ template <bool STATS, bool SKYMIS>
 __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const RenderArgs a) {
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
+    __shared__ uint32_t s_exhausted;  // bit q: a wave of this workgroup found task queue q exhausted
+    if (threadIdx.x == 0) s_exhausted = 0u;
+    __syncthreads();
     const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;
     TaskPool pool;
     pool.queue = blockIdx.x & (a.n_queues - 1u);
@@ -517,7 +535,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
         if (n_wait >= kShadeBatch || n_trav == 0) {
             uint32_t task = 0;
             const bool want = waiting && !have;
-            const int took = take_task(pool, a.task_counters, a.n_queues, n_tasks, want, task);
+            const int took = take_task(pool, a.task_counters, &s_exhausted, a.n_queues, n_tasks, want, task);
             finished = finished || took == kTaskExhausted;
             if (took == kTaskGot) {
                 const uint32_t entry = task / a.n_blocks;
