@@ -275,6 +275,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: a collective that never completes must not hang the job silently; this process ends itself with a message
+    # (the launcher then ends the others) when warm-up + timed steps take longer than IR_BENCH_WATCHDOG_S (default 900 s)
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("IR_BENCH_WATCHDOG_S", "900"))
+
+        def _stalled():
+            sys.stderr.write("bench.py rank %d: no progress for %.0f s (exchange: %s); giving up\n" % (rank, limit, exchange))
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(limit, _stalled)
+        watchdog.daemon = True
+        watchdog.start()
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -285,6 +300,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if watchdog is not None:
+        watchdog.cancel()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

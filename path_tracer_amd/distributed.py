@@ -88,9 +88,12 @@ class NativeExchange:
         import ctypes as C
         self.tracer, self.rank, self.world = tracer, int(rank), int(world)
         buf = C.create_string_buffer(_capi.IR_COMM_ID_BYTES)
+        ident = None
         if self.rank == 0:
-            _capi.check(None, _capi.lib.ir_comm_unique_id(buf))
-        ident = buf.raw if self.rank == 0 else None
+            # a failure here (no RCCL on this host) must still reach the broadcast below, or the other ranks wait for
+            # ever: they receive None and every rank raises together
+            if _capi.lib.ir_comm_unique_id(buf) == _capi.IR_OK:
+                ident = buf.raw
         if self.world > 1:
             if broadcast_id is None:
                 box = [ident]
@@ -99,7 +102,8 @@ class NativeExchange:
             else:
                 ident = broadcast_id(ident)
         if not isinstance(ident, (bytes, bytearray)) or len(ident) != _capi.IR_COMM_ID_BYTES:
-            raise ValueError("rendezvous id must be %d bytes" % _capi.IR_COMM_ID_BYTES)
+            raise ValueError("no rendezvous id of %d bytes (rank 0: %s)" % (
+                _capi.IR_COMM_ID_BYTES, (_capi.lib.ir_last_global_error() or b"").decode("utf-8", "replace") or "not received"))
         _capi.check(tracer._ctx, _capi.lib.ir_comm_init(tracer._ctx, bytes(ident), self.rank, self.world))
 
     def combine(self, root=0):
