@@ -324,7 +324,7 @@ def main():
                 want = spp * (world if partition == "samples" else 1)
                 exchange_info["verified_counts"] = bool((cc == want).all())
 
-    # ---- roofline of the dominant kernel (render_kernel), rank 0 only
+    # ---- roofline of the dominant kernel (the persistent path kernel), rank 0 only
     out = None
     if rank == 0:
         ms = [m for m, _ in kernel_ms]

@@ -374,7 +374,7 @@ struct LbvhView {
 };
 
 // Traversal state of one ray.  A traversal is cursor_begin + cursor_step until cur == kCursorDone: the integrator's
-// LBVH kernel interleaves steps of different lanes' rays with shading (render_lbvh_kernel), trace_lbvh runs one to
+// LBVH kernel interleaves steps of different lanes' rays with shading (paths_lbvh_kernel), trace_lbvh runs one to
 // the end.  The stack lives outside (LDS on the device: entry k of this lane at stack[k * stride]).
 constexpr int kCursorDone = 0x7fffffff;
 PT_DEV float box_rcp(float x) {

@@ -1,11 +1,11 @@
 // pt_kernels.hip — gfx950 (CDNA4, wave64) kernels of the InsploRay integrator.
 //
-// render_kernel: one lane owns one pixel and runs its samples in order (regeneration loop): when a path
-// ends, the lane adds it to its running sum and restarts from the pixel's primary hit with the next sample
-// index.  The primary ray has no jitter (pinhole_camera.rs:81-84), so ray generation and the first
-// closest-hit are shared by all samples of the pixel; everything after it is per sample.  Per-pixel sums
-// are therefore formed in exactly the order of the reference (one sample per render() call,
-// tile_buffer.rs:24-28 -> full_buffer.rs:107-125), which makes them bit-comparable to the CPU oracle.
+// primary_kernel -> paths_kernel | paths_lbvh_kernel -> merge_kernel ("Schedule" below): a lane runs TASKS, one sample
+// block of one pixel each, its samples in order (regeneration loop): when a path ends, the lane adds it to the block sum
+// and restarts from the pixel's primary hit with the next sample index.  The primary ray has no jitter
+// (pinhole_camera.rs:81-84), so ray generation and the first closest-hit are shared by all samples of the pixel;
+// everything after it is per sample.  Block sums are formed in exactly the order of the reference (one sample per
+// render() call, tile_buffer.rs:24-28 -> full_buffer.rs:107-125), which makes them bit-comparable to the CPU oracle.
 // The sphere SoA buffer is staged in LDS once per workgroup and read wave-uniformly (LDS broadcast).
 #include "pt_kernels.h"
 

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void wf_bounce(const WfArgs a) {
 // finished its path takes the next one instead of waiting for the wave (paths are independent here: nothing ties a
 // lane to a pixel).  A wave owns a chunk of kWfChunk consecutive input entries and a chunk of output slots at a time
 // (one global atomic per chunk); inside a chunk, lanes are served with ballot + mbcnt.  Unused output slots of a
-// chunk are marked empty (idx = -1) and skipped by the next stage.  Lane states as in render_lbvh_kernel: at an inner
+// chunk are marked empty (idx = -1) and skipped by the next stage.  Lane states as in paths_lbvh_kernel: at an inner
 // node, at a leaf, or waiting for the shading block (finish a landed ray / shade a fresh path).
 // ----------------------------------------------------------------------------------------------------
 constexpr uint32_t kWfChunk = 256;
