@@ -220,3 +220,30 @@ def test_sky_edited_in_place_is_uploaded_again(pta, tracer, oracle):
     want, _, _, _ = oracle.render(ocam, scene, spp, bounces=5, rr_start=2, seed=7, math_mode=1)
     assert np.array_equal(after.view(np.uint32), want.view(np.uint32))
     assert not np.array_equal(after, before)
+
+
+def test_launch_timers_and_lane_profile(pta, tracer):
+    """ir_last_kernel_ms / ir_last_paths_kernel_ms / ir_get_lane_profile: what bench.py's roofline object is built from.
+    The path kernel's time lies inside the launch sequence's; the lane profile counts every path sample once at the loop
+    top per bounce, never more than 64 lanes per wave execution, and is only there after a statistics render."""
+    from path_tracer_amd import workloads as W
+    w, h, spp = 320, 180, 32
+    scene = W.scene_s1()
+    tracer.set_active_camera(W.default_camera(w, h))
+    tracer.set_integrator(bounces=8, max_compulsory_bounces=2, seed=SEED)
+    tracer.render(scene, w, h, False, spp=spp)
+    seq_ms, launches = tracer.last_kernel_ms()
+    paths_ms = tracer.last_paths_kernel_ms()
+    assert launches == 1 and 0.0 < paths_ms <= seq_ms < 1000.0
+    with pytest.raises(pta.InsplorayError):
+        tracer.get_lane_profile()  # no statistics render yet
+    tracer.enable_stats()
+    tracer.render(scene, w, h, False, spp=spp)
+    st = tracer.get_stats()
+    prof = tracer.get_lane_profile()
+    waves, lanes = prof["loop"]
+    assert waves > 0 and lanes <= 64 * waves
+    # a lane passes the loop top once per hit it shades (the primary hit of every sample of a path pixel included)
+    assert lanes == st["hits"]
+    for k in ("roulette", "hit", "sky"):
+        assert prof[k][0] <= waves and prof[k][1] <= lanes
