@@ -92,17 +92,22 @@ PT_DEV f3 sky_eval(const RenderArgs& a, f3 dir) {
     return mk3(a.sky[0], a.sky[1], a.sky[2]);
 }
 #if defined(__HIPCC__)
-// (x, y) of this lane: workgroup `wg` of a 1D grid over the 16x16 blocks of the owned 64x64 tiles; waves are 8x8 pixels.
-__device__ __forceinline__ bool lane_pixel(uint32_t wg, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world, uint32_t w,
-                                           uint32_t h, uint32_t& x, uint32_t& y) {
+// (x, y) of a lane: thread `tid` (0..255) of workgroup `wg` of a 1D grid over the 16x16 blocks of the owned 64x64 tiles;
+// waves are 8x8 pixels.
+__device__ __forceinline__ bool block_pixel(uint32_t wg, uint32_t tid, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world,
+                                            uint32_t w, uint32_t h, uint32_t& x, uint32_t& y) {
     const uint32_t k = wg / kBlocksPerTile;
     const uint32_t sub = wg % kBlocksPerTile;
     const uint32_t tile = tile_rank + k * tile_world;
     const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
     x = tx * kTile + (sub & 3) * kBlockEdge + (wave & 1) * 8 + (lane & 7);
     y = ty * kTile + (sub >> 2) * kBlockEdge + (wave >> 1) * 8 + (lane >> 3);
     return x < w && y < h;
+}
+__device__ __forceinline__ bool lane_pixel(uint32_t wg, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world, uint32_t w,
+                                           uint32_t h, uint32_t& x, uint32_t& y) {  // a 256-thread workgroup per block
+    return block_pixel(wg, threadIdx.x, tiles_x, tile_rank, tile_world, w, h, x, y);
 }
 __device__ __forceinline__ void stage_spheres(float4* s_sph, const float4* __restrict__ g, uint32_t n) {
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {

@@ -74,7 +74,25 @@ enum { kTaskNone = 0, kTaskGot = 1, kTaskExhausted = -1 };  // kTaskNone: not as
 struct TaskPool {
     uint32_t next = 0, end = 0;     // wave-uniform: unclaimed ids [next, end) of the wave's current chunk
     uint32_t queue = 0, tried = 0;  // current queue; queues this wave has found exhausted
+    uint32_t dyn_base = 0;          // ids below it were dealt out statically (task_pool_begin); the queues hold the rest
 };
+// The first chunk of every wave is its own: wave w of the grid starts with the ids [64 w, 64 w + 64) without asking
+// anybody (a launch's first 7 168 requests would otherwise queue up behind 16 addresses, and a 1-spp interactive frame,
+// whose tasks number about as many as the resident lanes, needs no atomic at all).  The queues hold what is left.
+__device__ __forceinline__ TaskPool task_pool_begin(uint32_t n_tasks, uint32_t n_queues) {
+    TaskPool pool;
+    const uint32_t waves_per_wg = blockDim.x >> 6;
+    const uint32_t wave = blockIdx.x * waves_per_wg + (threadIdx.x >> 6);
+    const uint64_t capacity = (uint64_t)gridDim.x * waves_per_wg * kTaskChunk;
+    pool.dyn_base = capacity < n_tasks ? (uint32_t)capacity : n_tasks;
+    const uint64_t first = (uint64_t)wave * kTaskChunk;
+    if (first < pool.dyn_base) {
+        pool.next = (uint32_t)first;
+        pool.end = first + kTaskChunk < pool.dyn_base ? (uint32_t)first + kTaskChunk : pool.dyn_base;
+    }
+    pool.queue = blockIdx.x & (n_queues - 1u);
+    return pool;
+}
 __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uint32_t* s_exhausted, uint32_t n_queues, uint32_t n_tasks, bool want,
                                          uint32_t& task) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
@@ -82,7 +100,8 @@ __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uin
     const uint32_t n = (uint32_t)__builtin_popcountll(m), avail = pool.end - pool.next;
     uint32_t fresh = 0, fresh_n = 0;
     if (n > avail) {  // wave-uniform: one more chunk (n <= 64 = kTaskChunk)
-        const uint32_t per = task_queue_span(n_tasks, n_queues);
+        const uint32_t n_dyn = n_tasks - pool.dyn_base;  // ids of the queues, numbered from dyn_base
+        const uint32_t per = task_queue_span(n_dyn, n_queues);
         const int leader = __builtin_ctzll(m);
         while (pool.tried < n_queues) {
             // What the workgroup's other waves already found out saves the failing atomic: at the end of a launch every
@@ -91,7 +110,7 @@ __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uin
             const uint32_t known = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)s_exhausted);
             // (a queue without ids — a launch smaller than the queues — needs no probe either.  One word in memory for
             // what OTHER workgroups found was tried too: its atomics serialise like the cursors', C1 +50 % time.)
-            if (((known >> pool.queue) & 1u) || pool.queue * per >= n_tasks) {
+            if (((known >> pool.queue) & 1u) || pool.queue * per >= n_dyn) {
                 pool.queue = (pool.queue + 1u) & (n_queues - 1u);
                 pool.tried++;
                 continue;
@@ -100,10 +119,10 @@ __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uin
             if ((int)(threadIdx.x & 63u) == leader) v = atomicAdd(counters + (1u + pool.queue) * kTaskCounterStride, kTaskChunk);
             v = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
             const uint32_t qbeg = pool.queue * per;  // (< 2^32: launch_render bounds n_tasks)
-            if (qbeg < n_tasks) {
-                const uint32_t qlen = (n_tasks - qbeg < per) ? n_tasks - qbeg : per;
+            if (qbeg < n_dyn) {
+                const uint32_t qlen = (n_dyn - qbeg < per) ? n_dyn - qbeg : per;
                 if (v < qlen) {
-                    fresh = qbeg + v;
+                    fresh = pool.dyn_base + qbeg + v;
                     fresh_n = (qlen - v < kTaskChunk) ? qlen - v : kTaskChunk;
                     break;
                 }
@@ -271,8 +290,7 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
     if (threadIdx.x == 0) s_exhausted = 0u;
     stage_spheres(s_sph, a.spheres, a.n_spheres);  // (ends with the barrier that publishes s_exhausted too)
     const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
-    TaskPool pool;
-    pool.queue = blockIdx.x & (a.n_queues - 1u);
+    TaskPool pool = task_pool_begin(n_tasks, a.n_queues);
 
     // per-lane work statistics (STATS only): samples, traces, discriminant >= 0 tests, hits
     uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
@@ -474,8 +492,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     if (threadIdx.x == 0) s_exhausted = 0u;
     __syncthreads();
     const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;
-    TaskPool pool;
-    pool.queue = blockIdx.x & (a.n_queues - 1u);
+    TaskPool pool = task_pool_begin(n_tasks, a.n_queues);
     uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
     WorkCounters wc = {0, 0, 0};
     // lane-activity profile (STATS only; ir_get_lane_profile): rounds of the wave loop (lanes with work left), shading
@@ -807,9 +824,11 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     const bool skymis = a.sky_marginal != nullptr;
     const uint64_t max_tasks = (uint64_t)a.wgs_per_layer * 256u * a.n_blocks;
     // Queues: one address serves 100 .. 300 M atomics/s chip-wide.  Long blocks on a big frame ask rarely (C2: 10 M/s)
-    // and run 1.5 % faster on a single queue (measured on one box, tools/ab_bench.sh); short blocks or few tasks per wave
+    // and run 1.5 % faster on a single queue (measured on one box, tools/ab_bench.sh); short tasks (a 1-spp interactive
+    // frame is a task per pixel: 4K at 1 spp took 1.0 ms behind one cursor) or few tasks per wave
     // (C1: every wave asks in the first microseconds, then every few iterations) need the requests spread out.
-    a.n_queues = (a.sample_block >= 64 && max_tasks >= (2ull << 20)) ? 1u : kTaskQueues;
+    const uint32_t task_samples = a.spp < a.sample_block ? a.spp : a.sample_block;  // (the last block may be shorter still)
+    a.n_queues = (task_samples >= 64 && max_tasks >= (2ull << 20)) ? 1u : kTaskQueues;
     static const int forced_queues = getenv("IR_DEBUG_TASK_QUEUES") ? atoi(getenv("IR_DEBUG_TASK_QUEUES")) : 0;  // tools/ only
     if (forced_queues >= 1 && forced_queues <= (int)kTaskQueues && (forced_queues & (forced_queues - 1)) == 0) a.n_queues = (uint32_t)forced_queues;
     const void* paths = nullptr;
