@@ -152,15 +152,55 @@ __device__ __forceinline__ int take_task(TaskPool& pool, uint32_t* counters, uin
     return pool.tried >= n_queues ? kTaskExhausted : kTaskNone;
 }
 
-// Primary pass.  grid = owned tiles x 16 workgroups of 16x16 pixels.
-template <int ACCEL, bool STATS>
-__global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
+// A pixel whose primary ray escapes (direction d0; disc0 = discriminant >= 0 tests of that trace): the launch's samples
+// of the pixel, merged into the accumulator.
+template <bool STATS>
+__device__ __forceinline__ void finish_sky_pixel(const RenderArgs& a, uint32_t pixel, f3 d0, uint32_t disc0) {
+    // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89).  Its block sums are
+    // the same sequential adds a path lane would make (one full block, and the shorter last one on the way), and they
+    // are merged right here, in block order like merge_kernel does: a sky pixel never enters the task list.
+    f3 light = mk3(0.0f, 0.0f, 0.0f);
+    if (a.bounces != 0) light = light + sky_eval(a, d0) * mk3(1.0f, 1.0f, 1.0f);
+    const uint32_t n_full = a.spp / a.sample_block, rem = a.spp % a.sample_block;
+    const uint32_t len = n_full ? a.sample_block : rem;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), last = acc;
+    for (uint32_t s = 0; s < len; ++s) {
+        acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
+        if (s + 1 == rem) last = acc;
+    }
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t n = 0;
+    if (!a.fresh) {
+        t = a.sum[pixel];
+        n = a.counts[pixel];
+    }
+    for (uint32_t blk = 0; blk < n_full; ++blk) { t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w; }
+    if (rem) { t.x += last.x; t.y += last.y; t.z += last.z; t.w += last.w; }
+    a.sum[pixel] = t;
+    a.counts[pixel] = n + a.spp;
+    if (STATS) {  // algorithmic counts, as the reference would execute them: the primary ray per sample
+        atomicAdd(&a.stats[0], (unsigned long long)a.spp);
+        if (a.bounces != 0) {
+            atomicAdd(&a.stats[1], (unsigned long long)a.spp);
+            atomicAdd(&a.stats[2], (unsigned long long)a.spp * a.n_spheres);
+            atomicAdd(&a.stats[3], (unsigned long long)disc0 * a.spp);
+        }
+    }
+}
+
+// Primary pass.  One lane per owned pixel; a workgroup of WG threads covers WG / 256 neighbouring 16x16 blocks of a tile
+// (grid = owned tiles x 16 x 256 / WG).  The brute-force instantiation runs 1 024 threads: the workgroup's one atomic on the
+// list length is what a 1-spp frame waits for (1080p: 8 100 workgroups of 256 queue up for ~70 us behind that address).
+template <int ACCEL, bool STATS, int WG = 256>
+__global__ __launch_bounds__(WG) void primary_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
-    __shared__ uint32_t s_wave_hits[4], s_list_base;
+    constexpr uint32_t kWaves = WG / 64;
+    __shared__ uint32_t s_wave_hits[kWaves], s_list_base;
     if constexpr (ACCEL == kAccelLinear) stage_spheres(s_sph, a.spheres, a.n_spheres);
     if (a.task_counters_next && blockIdx.x == 0 && threadIdx.x <= kTaskQueues) a.task_counters_next[threadIdx.x * kTaskCounterStride] = 0u;
     uint32_t x, y;
-    const bool valid = lane_pixel(blockIdx.x, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y);
+    const bool valid = block_pixel(blockIdx.x * (WG / 256) + (threadIdx.x >> 8), threadIdx.x & 255u, a.tiles_x, a.tile_rank, a.tile_world,
+                                   a.w, a.h, x, y);
     const uint32_t pixel = y * a.w + x;
     Ray r0;
     r0.o = r0.d = mk3(0.0f, 0.0f, 0.0f);
@@ -187,7 +227,8 @@ __global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
     if ((threadIdx.x & 63u) == 0u) s_wave_hits[wave] = (uint32_t)__builtin_popcountll(hit_mask);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t total = s_wave_hits[0] + s_wave_hits[1] + s_wave_hits[2] + s_wave_hits[3];
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < kWaves; ++k) total += s_wave_hits[k];
         s_list_base = total ? atomicAdd(&a.task_counters[0], total) : 0u;
     }
     __syncthreads();
@@ -206,36 +247,7 @@ __global__ __launch_bounds__(256) void primary_kernel(const RenderArgs a) {
             a.counts[pixel] = 0u;
         }
     } else {
-        // every sample of this pixel is sky(d0) * (1,1,1) added to a zero light (integrator.rs:84-89).  Its block sums are
-        // the same sequential adds a path lane would make (one full block, and the shorter last one on the way), and they
-        // are merged right here, in block order like merge_kernel does: a sky pixel never enters the task list.
-        f3 light = mk3(0.0f, 0.0f, 0.0f);
-        if (a.bounces != 0) light = light + sky_eval(a, r0.d) * mk3(1.0f, 1.0f, 1.0f);
-        const uint32_t n_full = a.spp / a.sample_block, rem = a.spp % a.sample_block;
-        const uint32_t len = n_full ? a.sample_block : rem;
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), last = acc;
-        for (uint32_t s = 0; s < len; ++s) {
-            acc.x += light.x; acc.y += light.y; acc.z += light.z; acc.w += 1.0f;
-            if (s + 1 == rem) last = acc;
-        }
-        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t n = 0;
-        if (!a.fresh) {
-            t = a.sum[pixel];
-            n = a.counts[pixel];
-        }
-        for (uint32_t blk = 0; blk < n_full; ++blk) { t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w; }
-        if (rem) { t.x += last.x; t.y += last.y; t.z += last.z; t.w += last.w; }
-        a.sum[pixel] = t;
-        a.counts[pixel] = n + a.spp;
-        if (STATS) {  // algorithmic counts, as the reference would execute them: the primary ray per sample
-            atomicAdd(&a.stats[0], (unsigned long long)a.spp);
-            if (a.bounces != 0) {
-                atomicAdd(&a.stats[1], (unsigned long long)a.spp);
-                atomicAdd(&a.stats[2], (unsigned long long)a.spp * a.n_spheres);
-                atomicAdd(&a.stats[3], (unsigned long long)wc0.disc * a.spp);
-            }
-        }
+        finish_sky_pixel<STATS>(a, pixel, r0.d, wc0.disc);
     }
     if (STATS) {  // executed acceleration-structure work of the shared primary trace: once per launch
         atomicAdd(&a.stats[5], (unsigned long long)wc0.nodes);
@@ -268,14 +280,21 @@ __device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t
 }
 // The block sum leaves the lane: the reference's merge of one TileAccumulator pixel (full_buffer.rs:107-125), deferred to
 // merge_kernel when the launch has several blocks.
+// DIRECT (paths_kernel without a primary pass): nobody zeroed the pixel of a frame that starts with this launch.
+template <bool DIRECT = false>
 __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t) {
-    if (a.partials) {
+    if (!DIRECT && a.partials) {
         a.partials[t.task] = t.acc;
     } else {  // a single block (task id = list entry): the whole launch of this pixel
-        float4 v = a.sum[t.pixel];
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t n = 0;
+        if (!DIRECT || !a.fresh) {
+            v = a.sum[t.pixel];
+            n = a.counts[t.pixel];
+        }
         v.x += t.acc.x; v.y += t.acc.y; v.z += t.acc.z; v.w += t.acc.w;
         a.sum[t.pixel] = v;
-        a.counts[t.pixel] += a.spp;
+        a.counts[t.pixel] = n + a.spp;
     }
 }
 
@@ -283,14 +302,20 @@ __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t
 // the sky's distribution and traced as a shadow ray; both strategies weighted with the balance heuristic.
 // WG: threads per workgroup.  256 everywhere, except that a scene whose spheres fill most of a CU's LDS (thousands of
 // spheres: one workgroup per CU) runs workgroups of 1024 threads, so that 16 waves share the one staged copy instead of 4.
-template <bool STATS, bool SKYMIS, int WG = 256>
+// DIRECT: a launch with a single sample block per pixel (the frontend's redraw: prepare_pixels adds one sample) has one
+// task per path pixel, and list and dispenser cost more than they balance (launch_render has the measurements: 1080p at
+// 1 spp 70 us instead of 160).  The DIRECT instantiation is a lane per pixel: no primary pass, no list, no counters;
+// grid = 16 x owned tiles workgroups of 256; a lane traces its pixel's primary ray, finishes a sky pixel on the spot
+// (finish_sky_pixel) and otherwise runs the pixel's block as its only task, through the same loop body.
+template <bool STATS, bool SKYMIS, int WG = 256, bool DIRECT = false>
 __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     __shared__ uint32_t s_exhausted;  // bit q: a wave of this workgroup found task queue q exhausted
     if (threadIdx.x == 0) s_exhausted = 0u;
     stage_spheres(s_sph, a.spheres, a.n_spheres);  // (ends with the barrier that publishes s_exhausted too)
-    const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
-    TaskPool pool = task_pool_begin(n_tasks, a.n_queues);
+    const uint32_t n_tasks = DIRECT ? 0u : a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
+    TaskPool pool;
+    if constexpr (!DIRECT) pool = task_pool_begin(n_tasks, a.n_queues);
 
     // per-lane work statistics (STATS only): samples, traces, discriminant >= 0 tests, hits
     uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
@@ -325,11 +350,48 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
     int idx = 0;
     f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
 
+    if constexpr (DIRECT) {  // the lane's pixel is its one task (what primary_kernel does for the listed launches)
+        static_assert(WG == 256, "a 16x16 block per workgroup");
+        if (a.task_counters_next && blockIdx.x == 0 && threadIdx.x <= kTaskQueues) a.task_counters_next[threadIdx.x * kTaskCounterStride] = 0u;
+        finished = true;
+        uint32_t x, y;
+        if (lane_pixel(blockIdx.x, a.tiles_x, a.tile_rank, a.tile_world, a.w, a.h, x, y)) {
+            const uint32_t pixel = y * a.w + x;
+            Ray r0;
+            if (a.rays) {
+                const float* p = a.rays + 6 * (size_t)pixel;
+                r0.o = mk3(p[0], p[1], p[2]);
+                r0.d = mk3(p[3], p[4], p[5]);
+            } else {
+                r0 = pinhole_ray(a.cam, x, y, a.w, a.h);
+            }
+            HitRec h0;
+            h0.t = kF32Max;
+            h0.idx = -1;
+            uint32_t disc0 = 0;
+            if (a.bounces != 0) h0 = trace_linear<STATS>(s_sph, a.n_spheres, r0.o, r0.d, disc0);
+            if (h0.idx >= 0) {
+                hit_geometry(s_sph[h0.idx], r0.o, r0.d, h0.t, p0.pos, p0.nrm);
+                p0.idx = h0.idx;
+                p0.pixel = t.pixel = pixel;
+                p0_disc = disc0;
+                t_spp = a.spp;  // (launch_render: a single block)
+                t_key = pixel_key(a.seed_lo, pixel);
+                t_base = a.sample_base;
+                have = true;
+                start = true;
+            } else {
+                finish_sky_pixel<STATS>(a, pixel, r0.d, disc0);
+            }
+        }
+    }
+
     for (;;) {
         // ---- lanes without a task take the next one
         uint32_t task = 0;
         const bool want = !have && !finished;
-        const int took = take_task(pool, a.task_counters, &s_exhausted, a.n_queues, n_tasks, want, task);
+        int took = kTaskNone;
+        if constexpr (!DIRECT) took = take_task(pool, a.task_counters, &s_exhausted, a.n_queues, n_tasks, want, task);
         // (a lane's three outcomes as one branch and one mask operation: a three-way branch costs the loop 40 register
         // copies per iteration)
         finished = finished || took == kTaskExhausted;
@@ -442,7 +504,7 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
                 t.acc.x += light.x; t.acc.y += light.y; t.acc.z += light.z; t.acc.w += 1.0f;
                 ++t.s;
                 if (t.s == t_spp) {
-                    end_task(a, t);
+                    end_task<DIRECT>(a, t);
                     if (STATS) n_samples += t_spp;
                     have = false;
                 } else {  // regenerate at the primary hit with the next sample index
@@ -776,7 +838,9 @@ hipError_t init_kernels() {
     const void* big_lds[] = {(const void*)paths_kernel<false, false>,          (const void*)paths_kernel<true, false>,
                              (const void*)paths_kernel<false, true>,           (const void*)paths_kernel<true, true>,
                              (const void*)paths_kernel<false, false, 1024>,    (const void*)paths_kernel<true, false, 1024>,
-                             (const void*)primary_kernel<kAccelLinear, false>, (const void*)primary_kernel<kAccelLinear, true>,
+                             (const void*)paths_kernel<false, false, 256, true>, (const void*)paths_kernel<true, false, 256, true>,
+                             (const void*)paths_kernel<false, true, 256, true>,  (const void*)paths_kernel<true, true, 256, true>,
+                             (const void*)primary_kernel<kAccelLinear, false, 1024>, (const void*)primary_kernel<kAccelLinear, true, 1024>,
                              (const void*)primary_hits_kernel<kAccelLinear>};
     for (const void* f : big_lds) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -822,6 +886,21 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         if (e != hipSuccess) return e;
     }
     const bool skymis = a.sky_marginal != nullptr;
+    // A launch of a single block per pixel (prepare_pixels, the frontend's redraw, is one of 1 spp): one kernel, a lane per
+    // pixel (paths_kernel DIRECT).  Measured against list + tasks, which then has one task per path pixel (S1 scene,
+    // tools/direct_crossover.py, kernel ms): 1080p 1 spp 0.070 vs 0.160, 16 spp 0.35 vs 0.37, 128 spp 2.09 vs 2.32;
+    // 4K 1 spp 0.20 vs 0.32, 128 spp 6.50 vs 6.73; 800x450 0.032 vs 0.040, 128 spp 1.16 vs 1.14.
+    static const bool direct_ok = !getenv("IR_DEBUG_DIRECT") || atoi(getenv("IR_DEBUG_DIRECT")) != 0;  // tools/ only
+    if (accel != kAccelLbvh && a.n_blocks == 1 && direct_ok) {
+        const void* direct = stats ? (skymis ? (const void*)paths_kernel<true, true, 256, true> : (const void*)paths_kernel<true, false, 256, true>)
+                                   : (skymis ? (const void*)paths_kernel<false, true, 256, true> : (const void*)paths_kernel<false, false, 256, true>);
+        void* params[] = {(void*)&a};
+        if (paths_begin && (e = hipEventRecord(paths_begin, stream)) != hipSuccess) return e;
+        e = hipLaunchKernel(direct, dim3(a.wgs_per_layer), block, params, (size_t)a.n_spheres * sizeof(float4), stream);
+        if (e != hipSuccess) return e;
+        if (paths_end && (e = hipEventRecord(paths_end, stream)) != hipSuccess) return e;
+        return hipSuccess;
+    }
     const uint64_t max_tasks = (uint64_t)a.wgs_per_layer * 256u * a.n_blocks;
     // Queues: one address serves 100 .. 300 M atomics/s chip-wide.  Long blocks on a big frame ask rarely (C2: 10 M/s)
     // and run 1.5 % faster on a single queue (measured on one box, tools/ab_bench.sh); short tasks (a 1-spp interactive
@@ -848,8 +927,8 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         // occupancy experiments only (tools/): IR_DEBUG_LDS_PAD=<bytes> pads the workgroup's LDS allocation
         static const size_t pad = getenv("IR_DEBUG_LDS_PAD") ? (size_t)atol(getenv("IR_DEBUG_LDS_PAD")) : 0;
         if (lds + pad <= kMaxLdsSpheres * sizeof(float4)) lds += pad;
-        if (stats) hipLaunchKernelGGL((primary_kernel<kAccelLinear, true>), dim3(a.wgs_per_layer), block, lds, stream, a);
-        else hipLaunchKernelGGL((primary_kernel<kAccelLinear, false>), dim3(a.wgs_per_layer), block, lds, stream, a);
+        if (stats) hipLaunchKernelGGL((primary_kernel<kAccelLinear, true, 1024>), dim3(a.wgs_per_layer / 4), dim3(1024), lds, stream, a);
+        else hipLaunchKernelGGL((primary_kernel<kAccelLinear, false, 1024>), dim3(a.wgs_per_layer / 4), dim3(1024), lds, stream, a);
         paths = stats ? (skymis ? (const void*)paths_kernel<true, true> : (const void*)paths_kernel<true, false>)
                       : (skymis ? (const void*)paths_kernel<false, true> : (const void*)paths_kernel<false, false>);
         // more than 40 KB of spheres: fewer than four 256-thread workgroups fit a CU; let 16 waves share one staged copy

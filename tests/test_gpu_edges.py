@@ -247,3 +247,41 @@ def test_launch_timers_and_lane_profile(pta, tracer):
     assert lanes == st["hits"]
     for k in ("roulette", "hit", "sky"):
         assert prof[k][0] <= waves and prof[k][1] <= lanes
+
+
+_SINGLE_BLOCK_FRAMES = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import path_tracer_amd as pta
+from path_tracer_amd import _capi, workloads as W
+rt = pta.RayTracer(0, 0, device=0)
+rt.set_integrator(bounces=8, max_compulsory_bounces=2, seed=W.RNG_SEED)
+for sky, mode in ((None, _capi.IR_SKY_SAMPLING_BSDF), ("synthetic", _capi.IR_SKY_SAMPLING_BSDF), ("synthetic", _capi.IR_SKY_SAMPLING_MIS)):
+    scene = W.scene_s1(skybox=sky)
+    rt.set_sky_sampling(mode)
+    for (w, h) in ((203, 117), (64, 64)):
+        rt.set_active_camera(W.default_camera(w, h))
+        rt.render(scene, w, h, False, spp=1)       # a frame that starts with the launch
+        rt.render(scene, w, h, True, spp=1)        # prepare_pixels: one more sample
+        rt.enable_stats()                          # (applies to the next render)
+        rt.render(scene, w, h, True, spp=37)       # a longer single block, the statistics instantiation
+        s, c = rt.get_radiance()
+        st = rt.get_stats()
+        print(hashlib.sha256(s.tobytes() + c.tobytes()).hexdigest(), sorted(st.items()))
+rt.close()
+"""
+
+
+def test_single_block_launch_same_bits_with_and_without_task_list(pta):
+    """A launch of one sample block per pixel runs a lane per pixel (paths_kernel DIRECT); with IR_DEBUG_DIRECT=0 the same
+    launch goes through the primary pass, the list and the task dispenser.  Same sums, same counts, same statistics."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for direct in ("1", "0"):
+        env = dict(os.environ, IR_DEBUG_DIRECT=direct)
+        r = subprocess.run([sys.executable, "-c", _SINGLE_BLOCK_FRAMES, root], env=env, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 6, outs

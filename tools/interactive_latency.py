@@ -25,6 +25,8 @@ for (w, h) in [(800, 450), (1920, 1080), (3840, 2160)]:
     print(f"{w}x{h}: prepare_pixels {1e3*(t1-t0)/n:.3f} ms/frame (kernel {k:.3f} ms), prepare_pixels + get_output {1e3*(t2-t1)/n:.3f} ms/frame "
           f"-> {n/(t2-t1):.0f} fps, {rt.samples_accumulated()} spp accumulated", flush=True)
 rt.close()
+if '--frames-only' in sys.argv:
+    sys.exit(0)
 
 # The editor's pattern (frontend/src/viewport.rs:29-52 mutates the spheres, app.rs:84-99 redraws): every frame moves the
 # spheres, restarts the accumulation (render_updated) and presents.  The LBVH is rebuilt (or refitted) per frame.
