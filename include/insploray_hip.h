@@ -318,7 +318,7 @@ int ir_selftest_exact_math(ir_context* ctx, uint64_t* out_mismatches, uint32_t n
 /* -------------------------------------------------------------------------------------------------
  * EXR (file_formats/exr.rs:26-49: ExrImage::load_exr_image == exr::read_first_rgba_layer_from_file).
  * From-scratch reader: single/multi-part, scanline and tiled (level 0) files, HALF/FLOAT/UINT channels,
- * NONE/RLE/ZIPS/ZIP/PIZ/PXR24 compression (the lossy B44 and DWA are reported as unsupported: IR_EIO); the first layer
+ * NONE/RLE/ZIPS/ZIP/PIZ/PXR24/B44/B44A compression (the lossy DWAA/DWAB are reported as unsupported: IR_EIO); the first layer
  * that has R, G and B; alpha dropped; pixel (x,y) of the data window at y*width+x, row 0 = top of the file.
  * ir_exr_load allocates *out_rgb (w*h*3 floats) with malloc; release with ir_free.  Needs no GPU.
  * ir_exr_last_error() gives the message of the last failed EXR call on this thread.
@@ -326,7 +326,8 @@ int ir_selftest_exact_math(ir_context* ctx, uint64_t* out_mismatches, uint32_t n
 int ir_exr_load(const char* path, float** out_rgb, uint32_t* out_w, uint32_t* out_h);
 const char* ir_exr_last_error(void);
 /* Writer (fixtures, "save image" — a reference TODO, README.md:104): RGB scanline EXR; compression 0 = NONE,
- * 1 = RLE, 2 = ZIPS, 3 = ZIP, 4 = PIZ, 5 = PXR24 (rounds FLOAT samples to 24 bits); pixel_type 1 = HALF, 2 = FLOAT. */
+ * 1 = RLE, 2 = ZIPS, 3 = ZIP, 4 = PIZ, 5 = PXR24 (rounds FLOAT samples to 24 bits), 6 = B44, 7 = B44A (lossy, HALF samples
+ * only: 4x4 blocks in 14 bytes; FLOAT samples pass through unchanged); pixel_type 1 = HALF, 2 = FLOAT. */
 int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int compression, int pixel_type);
 /* The resolved frame as an 8-bit RGB PNG (the other half of "save image"): argb as ir_get_output_argb /
  * ir_map_output_argb return it (0xAARRGGBB, row 0 = bottom row, renderer.rs:164-169), written top-down; alpha is

@@ -1,5 +1,5 @@
-// exr_codecs.cpp — the two OpenEXR block codecs beyond zlib/RLE that lossless HDR environment maps are usually
-// stored with: PIZ (compression 4) and PXR24 (compression 5).  Written from the published description of the
+// exr_codecs.cpp — the OpenEXR block codecs beyond zlib/RLE: PIZ (compression 4) and PXR24 (5), which lossless HDR
+// environment maps are usually stored with, and the lossy fixed-rate B44 / B44A (6, 7).  Written from the published description of the
 // formats (OpenEXR "Technical Introduction" + the layout of the reference implementation's chunks); no OpenEXR,
 // tinyexr or `exr` crate source exists in this environment and no file written by another implementation is
 // available here, so these codecs are pinned only by their own round trips and hand-made vectors
@@ -608,6 +608,181 @@ bool pxr24_encode(const uint8_t* raw, const std::vector<int>& types, int bw, int
     out.resize(cn);
     if (compress2(out.data(), &cn, tmp.data(), (uLong)tmp.size(), 6) != Z_OK) return false;
     out.resize(cn);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- B44 / B44A
+// Lossy, fixed rate, HALF channels only (UINT / FLOAT channels travel uncompressed).  The block's data is channel after
+// channel (not line by line); a HALF channel is cut into 4x4 pixel blocks, row-major, the right column / bottom row
+// repeated where the block hangs over the edge.  The 16 half bit patterns s[i] are mapped to integers t[i] that order
+// like the numbers they stand for (negative: ~s, else s | 0x8000; NaN and infinity become 0x8000 = zero), and a block is
+// 14 bytes: t[0] (16 bits), a shift (6 bits) and 15 six-bit differences, biased by 32, along the chain
+// 0 -> 4 -> 8 -> 12 (down the first column), then column 0 -> 1, 1 -> 2, 2 -> 3 in each of the four rows; the shift is the
+// smallest for which every rounded difference fits.  B44A writes a block of 16 equal values as 3 bytes: t[0] and a
+// third byte that no 14-byte block can have (0xfc: a shift of 63).  A channel flagged pLinear in the header was passed
+// through exp(x / 8) before packing and needs 8 log(x) after unpacking (a 65 536-entry table the caller provides).
+namespace {
+inline int b44_shift_and_round(int x, int shift) {  // x / 2^shift, to nearest, ties to even
+    x <<= 1;
+    const int a = (1 << shift) - 1;
+    shift += 1;
+    const int b = (x >> shift) & 1;
+    return (x + a + b) >> shift;
+}
+
+int b44_pack(const uint16_t s[16], uint8_t b[14], bool flat_fields, bool exact_max) {
+    uint16_t t[16];
+    for (int i = 0; i < 16; ++i) {
+        if ((s[i] & 0x7c00) == 0x7c00) t[i] = 0x8000;
+        else if (s[i] & 0x8000) t[i] = (uint16_t)~s[i];
+        else t[i] = (uint16_t)(s[i] | 0x8000);
+    }
+    uint16_t t_max = 0;
+    for (int i = 0; i < 16; ++i) t_max = std::max(t_max, t[i]);
+    const int bias = 0x20;
+    int shift = -1, d[16], r[15], r_min, r_max;
+    do {
+        shift += 1;
+        for (int i = 0; i < 16; ++i) d[i] = b44_shift_and_round(t_max - t[i], shift);
+        r[0] = d[0] - d[4] + bias;   r[1] = d[4] - d[8] + bias;    r[2] = d[8] - d[12] + bias;
+        r[3] = d[0] - d[1] + bias;   r[4] = d[4] - d[5] + bias;    r[5] = d[8] - d[9] + bias;    r[6] = d[12] - d[13] + bias;
+        r[7] = d[1] - d[2] + bias;   r[8] = d[5] - d[6] + bias;    r[9] = d[9] - d[10] + bias;   r[10] = d[13] - d[14] + bias;
+        r[11] = d[2] - d[3] + bias;  r[12] = d[6] - d[7] + bias;   r[13] = d[10] - d[11] + bias; r[14] = d[14] - d[15] + bias;
+        r_min = r_max = r[0];
+        for (int i = 1; i < 15; ++i) {
+            r_min = std::min(r_min, r[i]);
+            r_max = std::max(r_max, r[i]);
+        }
+    } while (r_min < 0 || r_max > 0x3f);
+    if (r_min == bias && r_max == bias && flat_fields) {
+        b[0] = (uint8_t)(t[0] >> 8);
+        b[1] = (uint8_t)t[0];
+        b[2] = 0xfc;
+        return 3;
+    }
+    if (exact_max) t[0] = (uint16_t)(t_max - (d[0] << shift));  // the block's largest value comes back as exactly as it can
+    b[0] = (uint8_t)(t[0] >> 8);
+    b[1] = (uint8_t)t[0];
+    b[2] = (uint8_t)((shift << 2) | (r[0] >> 4));
+    b[3] = (uint8_t)((r[0] << 4) | (r[1] >> 2));
+    b[4] = (uint8_t)((r[1] << 6) | r[2]);
+    b[5] = (uint8_t)((r[3] << 2) | (r[4] >> 4));
+    b[6] = (uint8_t)((r[4] << 4) | (r[5] >> 2));
+    b[7] = (uint8_t)((r[5] << 6) | r[6]);
+    b[8] = (uint8_t)((r[7] << 2) | (r[8] >> 4));
+    b[9] = (uint8_t)((r[8] << 4) | (r[9] >> 2));
+    b[10] = (uint8_t)((r[9] << 6) | r[10]);
+    b[11] = (uint8_t)((r[11] << 2) | (r[12] >> 4));
+    b[12] = (uint8_t)((r[12] << 4) | (r[13] >> 2));
+    b[13] = (uint8_t)((r[13] << 6) | r[14]);
+    return 14;
+}
+
+inline void b44_from_ordered(uint16_t s[16]) {
+    for (int i = 0; i < 16; ++i) s[i] = (s[i] & 0x8000) ? (uint16_t)(s[i] & 0x7fff) : (uint16_t)~s[i];
+}
+
+void b44_unpack14(const uint8_t b[14], uint16_t s[16]) {  // (16-bit wrap-around arithmetic, like the packer's)
+    const unsigned shift = b[2] >> 2;  // < 13 (the caller took the 3-byte form otherwise)
+    const unsigned bias = 0x20u << shift;
+    auto step = [&](int from, unsigned six) { return (uint16_t)(s[from] + ((six & 0x3fu) << shift) - bias); };
+    s[0] = (uint16_t)((b[0] << 8) | b[1]);
+    s[4] = step(0, ((unsigned)b[2] << 4) | (b[3] >> 4));
+    s[8] = step(4, ((unsigned)b[3] << 2) | (b[4] >> 6));
+    s[12] = step(8, b[4]);
+    s[1] = step(0, b[5] >> 2);
+    s[5] = step(4, ((unsigned)b[5] << 4) | (b[6] >> 4));
+    s[9] = step(8, ((unsigned)b[6] << 2) | (b[7] >> 6));
+    s[13] = step(12, b[7]);
+    s[2] = step(1, b[8] >> 2);
+    s[6] = step(5, ((unsigned)b[8] << 4) | (b[9] >> 4));
+    s[10] = step(9, ((unsigned)b[9] << 2) | (b[10] >> 6));
+    s[14] = step(13, b[10]);
+    s[3] = step(2, b[11] >> 2);
+    s[7] = step(6, ((unsigned)b[11] << 4) | (b[12] >> 4));
+    s[11] = step(10, ((unsigned)b[12] << 2) | (b[13] >> 6));
+    s[15] = step(14, b[13]);
+    b44_from_ordered(s);
+}
+
+void b44_unpack3(const uint8_t b[3], uint16_t s[16]) {
+    s[0] = (uint16_t)((b[0] << 8) | b[1]);
+    for (int i = 1; i < 16; ++i) s[i] = s[0];
+    b44_from_ordered(s);
+}
+}  // namespace
+
+bool b44_decode(const uint8_t* data, size_t size, const std::vector<int>& types, const std::vector<const uint16_t*>& to_linear, int bw,
+                int bh, std::vector<uint8_t>& raw) {
+    if (bw <= 0 || bh <= 0 || to_linear.size() != types.size()) return false;
+    size_t line_bytes = 0;
+    for (int t : types) line_bytes += (size_t)bw * (t == 1 ? 2 : 4);
+    raw.assign(line_bytes * (size_t)bh, 0);
+    const uint8_t *p = data, *const end = data + size;
+    size_t chan_off = 0;
+    for (size_t c = 0; c < types.size(); ++c) {
+        if (types[c] != 1) {  // uncompressed: bh rows of bw four-byte samples
+            const size_t row = (size_t)bw * 4;
+            if ((size_t)(end - p) < row * (size_t)bh) return false;
+            for (int y = 0; y < bh; ++y, p += row) std::memcpy(raw.data() + (size_t)y * line_bytes + chan_off, p, row);
+            chan_off += row;
+            continue;
+        }
+        for (int y = 0; y < bh; y += 4)
+            for (int x = 0; x < bw; x += 4) {
+                uint16_t s[16];
+                if (end - p < 3) return false;
+                if (p[2] >= (13 << 2)) {
+                    b44_unpack3(p, s);
+                    p += 3;
+                } else {
+                    if (end - p < 14) return false;
+                    b44_unpack14(p, s);
+                    p += 14;
+                }
+                if (to_linear[c])
+                    for (int i = 0; i < 16; ++i) s[i] = to_linear[c][s[i]];
+                for (int j = 0; j < 4 && y + j < bh; ++j) {
+                    uint8_t* o = raw.data() + (size_t)(y + j) * line_bytes + chan_off + (size_t)x * 2;
+                    for (int i = 0; i < 4 && x + i < bw; ++i) {
+                        *o++ = (uint8_t)(s[4 * j + i] & 0xff);
+                        *o++ = (uint8_t)(s[4 * j + i] >> 8);
+                    }
+                }
+            }
+        chan_off += (size_t)bw * 2;
+    }
+    return p == end;
+}
+
+bool b44_encode(const uint8_t* raw, const std::vector<int>& types, int bw, int bh, bool flat_fields, std::vector<uint8_t>& out) {
+    if (bw <= 0 || bh <= 0) return false;
+    size_t line_bytes = 0;
+    for (int t : types) line_bytes += (size_t)bw * (t == 1 ? 2 : 4);
+    out.clear();
+    size_t chan_off = 0;
+    for (int t : types) {
+        if (t != 1) {
+            const size_t row = (size_t)bw * 4;
+            for (int y = 0; y < bh; ++y) out.insert(out.end(), raw + (size_t)y * line_bytes + chan_off, raw + (size_t)y * line_bytes + chan_off + row);
+            chan_off += row;
+            continue;
+        }
+        auto at = [&](int x, int y) {  // edge pixels repeat
+            const uint8_t* q = raw + (size_t)std::min(y, bh - 1) * line_bytes + chan_off + (size_t)std::min(x, bw - 1) * 2;
+            return (uint16_t)(q[0] | (q[1] << 8));
+        };
+        for (int y = 0; y < bh; y += 4)
+            for (int x = 0; x < bw; x += 4) {
+                uint16_t s[16];
+                for (int j = 0; j < 4; ++j)
+                    for (int i = 0; i < 4; ++i) s[4 * j + i] = at(x + i, y + j);
+                uint8_t b[14];
+                const int n = b44_pack(s, b, flat_fields, true);
+                out.insert(out.end(), b, b + n);
+            }
+        chan_off += (size_t)bw * 2;
+    }
     return true;
 }
 

@@ -9,8 +9,8 @@
 //   chunks = [part] y size data (scanline) or [part] tx ty lx ly size data (tile), channel-planar lines,
 //   ZIP/ZIPS = zlib deflate over (byte de-interleave + delta predictor), RLE = the same filter + byte runs.
 // Supported: single- and multi-part files, scanline and tiled (level 0) parts, HALF / FLOAT / UINT samples,
-// compression NONE, RLE, ZIPS, ZIP, PIZ and PXR24 (the last two in exr_codecs.cpp).  The lossy B44(A) and
-// DWAA/DWAB are reported as unsupported.
+// compression NONE, RLE, ZIPS, ZIP, PIZ, PXR24 and the lossy B44 / B44A (the last four in exr_codecs.cpp).  DWAA/DWAB
+// are reported as unsupported.
 #include <zlib.h>
 
 #include <cmath>
@@ -71,6 +71,7 @@ struct Reader {
 struct Channel {
     std::string name;
     int type;  // 0 UINT, 1 HALF, 2 FLOAT
+    int plinear = 0;  // "perceptually linear" flag of the channel list: only B44(A) looks at it
     int xs, ys;
     size_t bytes() const { return type == 1 ? 2 : 4; }
 };
@@ -249,7 +250,7 @@ bool parse_header(Reader& r, Part& part) {
                 Channel c;
                 c.name = cn;
                 c.type = a.i32();
-                a.u8();
+                c.plinear = a.u8();
                 a.u8(); a.u8(); a.u8();
                 c.xs = a.i32();
                 c.ys = a.i32();
@@ -325,8 +326,23 @@ int set_err(int code, const std::string& msg) {
 }
 
 // decode one chunk's pixel bytes into `raw` (uncompressed size `expect`)
+// B44(A), channels flagged pLinear: half -> half(8 log x); non-finite and negative values -> 0.  (The published table is
+// generated with the library's own half type; this one rounds 8 log(x), evaluated in double, to the nearest half.)
+const uint16_t* b44_log_table() {
+    static const std::vector<uint16_t> table = [] {
+        std::vector<uint16_t> t(65536, 0);
+        for (uint32_t i = 0; i < 65536; ++i) {
+            if ((i & 0x7c00u) == 0x7c00u || (i & 0x8000u)) continue;
+            const float x = half_to_float((uint16_t)i);
+            t[i] = x > 0.0f ? float_to_half((float)(8.0 * std::log((double)x))) : float_to_half(-INFINITY);
+        }
+        return t;
+    }();
+    return table.data();
+}
+
 bool decode_block(int compression, const uint8_t* data, size_t size, size_t expect, std::vector<uint8_t>& raw,
-                  std::vector<uint8_t>& scratch, const std::vector<int>& types, int bw, int bh) {
+                  std::vector<uint8_t>& scratch, const std::vector<int>& types, const std::vector<int>& plinear, int bw, int bh) {
     if (compression == 0 || size == expect) {  // NONE, or stored raw because compression did not help
         if (size != expect) return false;
         raw.assign(data, data + size);
@@ -346,6 +362,12 @@ bool decode_block(int compression, const uint8_t* data, size_t size, size_t expe
     }
     if (compression == 4) return exr::piz_decode(data, size, types, bw, bh, raw) && raw.size() == expect;
     if (compression == 5) return exr::pxr24_decode(data, size, types, bw, bh, raw) && raw.size() == expect;
+    if (compression == 6 || compression == 7) {
+        std::vector<const uint16_t*> to_linear(types.size(), nullptr);
+        for (size_t c = 0; c < types.size(); ++c)
+            if (types[c] == 1 && plinear[c]) to_linear[c] = b44_log_table();
+        return exr::b44_decode(data, size, types, to_linear, bw, bh, raw) && raw.size() == expect;
+    }
     return false;
 }
 
@@ -422,7 +444,7 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
         }
     if (sel == parts.size()) return set_err(IR_EIO, "EXR file has no layer with R, G and B channels");
     const Part& p = parts[sel];
-    if (p.compression > 5) {
+    if (p.compression > 7) {
         static const char* names[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
         return set_err(IR_EIO, std::string("EXR compression ") + (p.compression < 10 ? names[p.compression] : "?") + " is not supported");
     }
@@ -440,8 +462,11 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
     std::unique_ptr<float, void (*)(void*)> img_owner(img, std::free);  // released to the caller on success only
     std::memset(img, 0, (size_t)W * H * 3 * sizeof(float));
     std::vector<uint8_t> raw, scratch;
-    std::vector<int> types;
-    for (const Channel& c : p.channels) types.push_back(c.type);
+    std::vector<int> types, plinear;
+    for (const Channel& c : p.channels) {
+        types.push_back(c.type);
+        plinear.push_back(c.plinear);
+    }
     const int lpb = p.tiled ? 0 : lines_per_block(p.compression);
 
     auto bail = [&](const char* m) { return set_err(IR_EIO, m); };
@@ -476,7 +501,7 @@ int load_from_memory(const uint8_t* bytes, size_t n, float** out_rgb, uint32_t* 
         const int32_t size = c.i32();
         if (!c.ok || size < 0 || !c.need((size_t)size)) return bail("truncated EXR chunk");
         const size_t expect = (size_t)bw * bh * bytes_per_pixel;
-        if (!decode_block(p.compression, bytes + c.pos, (size_t)size, expect, raw, scratch, types, bw, bh)) return bail("corrupt EXR chunk data");
+        if (!decode_block(p.compression, bytes + c.pos, (size_t)size, expect, raw, scratch, types, plinear, bw, bh)) return bail("corrupt EXR chunk data");
         // lines are channel-planar: for each line, for each channel (file order), bw samples
         for (int ly = 0; ly < bh; ++ly) {
             const uint8_t* line = raw.data() + (size_t)ly * bw * bytes_per_pixel;
@@ -553,8 +578,8 @@ int ir_exr_load(const char* path, float** out_rgb, uint32_t* out_w, uint32_t* ou
 
 int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int compression, int pixel_type) {
     if (!path || !rgb || w == 0 || h == 0) return set_err(IR_EINVAL, "ir_exr_save: NULL or empty image");
-    if (compression < 0 || compression > 5)
-        return set_err(IR_EINVAL, "ir_exr_save: compression must be 0 (NONE), 1 (RLE), 2 (ZIPS), 3 (ZIP), 4 (PIZ) or 5 (PXR24)");
+    if (compression < 0 || compression > 7)
+        return set_err(IR_EINVAL, "ir_exr_save: compression must be 0 (NONE), 1 (RLE), 2 (ZIPS), 3 (ZIP), 4 (PIZ), 5 (PXR24), 6 (B44) or 7 (B44A)");
     if (pixel_type != 1 && pixel_type != 2) return set_err(IR_EINVAL, "ir_exr_save: pixel_type must be 1 (HALF) or 2 (FLOAT)");
     return guarded("ir_exr_save", [&]() -> int {
     std::vector<uint8_t> o;
@@ -628,8 +653,9 @@ int ir_exr_save(const char* path, const float* rgb, uint32_t w, uint32_t h, int 
             }
         } else if (compression >= 4) {
             const std::vector<int> types(3, pixel_type);
-            const bool ok = compression == 4 ? exr::piz_encode(raw.data(), types, (int)w, (int)bh, comp)
-                                             : exr::pxr24_encode(raw.data(), types, (int)w, (int)bh, comp);
+            const bool ok = compression == 4   ? exr::piz_encode(raw.data(), types, (int)w, (int)bh, comp)
+                            : compression == 5 ? exr::pxr24_encode(raw.data(), types, (int)w, (int)bh, comp)
+                                               : exr::b44_encode(raw.data(), types, (int)w, (int)bh, compression == 7, comp);
             if (!ok) return set_err(IR_EIO, "EXR block encoder failed");
             if (comp.size() < raw.size()) {
                 payload = comp.data();

@@ -29,7 +29,7 @@ def test_float_round_trip_is_exact(tmp_path, comp, w, h):
     assert back.pixels_buffer.tobytes() == img.pixels_buffer.tobytes()
 
 
-@pytest.mark.parametrize("comp", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("comp", [0, 1, 3, 4, 5])  # (the lossy 6 and 7: tests/test_exr_b44.py)
 def test_half_round_trip(tmp_path, comp):
     w, h = 40, 21
     src = _img(w, h, 5)
@@ -190,8 +190,8 @@ def test_errors_are_results_not_crashes(tmp_path):
     w, h = 4, 2
     planes = {k: np.zeros((h, w)) for k in "BGR"}
     p.write_bytes(_handmade([(k, 2) for k in "BGR"], w, h, 0, 0, planes, comp=0).replace(
-        b"compression\0compression\0\x01\0\0\0\0", b"compression\0compression\0\x01\0\0\0\x06"))
-    with pytest.raises(pta.InsplorayError, match="B44"):
+        b"compression\0compression\0\x01\0\0\0\0", b"compression\0compression\0\x01\0\0\0\x08"))
+    with pytest.raises(pta.InsplorayError, match="DWAA"):
         pta.ExrImage.load_exr_image(p)
     # no RGB layer
     p.write_bytes(_handmade([("Y", 2)], w, h, 0, 0, {"Y": np.zeros((h, w))}))
@@ -445,6 +445,20 @@ def test_reader_under_address_sanitizer(tmp_path):
                     i = int(rng.integers(8, len(bad)))  # headers included: tile sizes, windows, counts
                     bad[i] ^= 1 << int(rng.integers(0, 8))
             add(f"{tag}{trial}.exr", bad)
+    for comp in (6, 7):  # B44 / B44A blocks from the writer, whole and damaged (tests/test_exr_b44.py has the format checks)
+        q = tmp_path / f"b44_{comp}.exr"
+        pta.ExrImage(_img(21, 37, comp), 21, 37).save(q, compression=comp, pixel_type=1)
+        base = q.read_bytes()
+        files.append(str(q))
+        for trial in range(100):
+            bad = bytearray(base)
+            if trial % 4 == 0:
+                bad = bad[: int(rng.integers(1, len(bad)))]
+            else:
+                for _ in range(int(rng.integers(1, 5))):
+                    i = int(rng.integers(8, len(bad)))
+                    bad[i] ^= 1 << int(rng.integers(0, 8))
+            add(f"b{comp}_{trial}.exr", bad)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
     r = subprocess.run([str(exe)] + files, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
