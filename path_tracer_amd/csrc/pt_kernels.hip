@@ -891,7 +891,8 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     // tools/direct_crossover.py, kernel ms): 1080p 1 spp 0.070 vs 0.160, 16 spp 0.35 vs 0.37, 128 spp 2.09 vs 2.32;
     // 4K 1 spp 0.20 vs 0.32, 128 spp 6.50 vs 6.73; 800x450 0.032 vs 0.040, 128 spp 1.16 vs 1.14.
     static const bool direct_ok = !getenv("IR_DEBUG_DIRECT") || atoi(getenv("IR_DEBUG_DIRECT")) != 0;  // tools/ only
-    if (accel != kAccelLbvh && a.n_blocks == 1 && direct_ok) {
+    // (not above 40 KB of spheres: there the listed launch shares one staged copy between 16 waves, see below)
+    if (accel != kAccelLbvh && a.n_blocks == 1 && direct_ok && (size_t)a.n_spheres * sizeof(float4) <= kBigWorkgroupFromLdsBytes) {
         const void* direct = stats ? (skymis ? (const void*)paths_kernel<true, true, 256, true> : (const void*)paths_kernel<true, false, 256, true>)
                                    : (skymis ? (const void*)paths_kernel<false, true, 256, true> : (const void*)paths_kernel<false, false, 256, true>);
         void* params[] = {(void*)&a};
