@@ -2,6 +2,8 @@
 radii, overlapping and coincident spheres, out-of-range material ids, emissive / black / over-unity albedos), camera
 poses, frame shapes that cut tiles and blocks, depth / roulette / spp / sample-block settings, sky kinds and filters,
 both closest-hit structures, both builders, both schedules, both sky estimators."""
+import os
+
 import numpy as np
 import pytest
 
@@ -75,7 +77,8 @@ def _random_case(rng, large=False):
 def test_random_configuration_bit_exact(pta, tracer, oracle, case):
     from path_tracer_amd import _capi
     large = isinstance(case, str)
-    rng = np.random.default_rng(9000 + (int(case[5:]) + 5000 if large else case))
+    # IR_FUZZ_SHIFT=<n> moves every case to another seed (one-off wider runs: IR_FUZZ_SHIFT=100000 pytest tests/test_gpu_fuzz.py)
+    rng = np.random.default_rng(9000 + int(os.environ.get("IR_FUZZ_SHIFT", "0")) + (int(case[5:]) + 5000 if large else case))
     scene, cam, w, h, cfg = _random_case(rng, large)
     if large and cfg["accel"] == "linear":
         cfg["accel"] = "auto"
