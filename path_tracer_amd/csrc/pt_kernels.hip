@@ -7,6 +7,8 @@
 // everything after it is per sample.  Block sums are formed in exactly the order of the reference (one sample per
 // render() call, tile_buffer.rs:24-28 -> full_buffer.rs:107-125), which makes them bit-comparable to the CPU oracle.
 // The sphere SoA buffer is staged in LDS once per workgroup and read wave-uniformly (LDS broadcast).
+// A launch of a single block per pixel (the frontend's 1-spp redraw) is one kernel instead: paths_kernel<.., DIRECT>, a
+// lane per pixel through the same loop body.
 #include "pt_kernels.h"
 
 #include <cstdlib>
@@ -51,8 +53,9 @@ __device__ __forceinline__ float4 sphere_at(const Args& a, const float4* s_sph, 
 //                    takes a task, runs its samples in order with path regeneration (when a path ends, the lane adds it
 //                    to the block sum and restarts at the pixel's primary hit with the next sample index), writes the
 //                    block sum and takes the next task — lanes never wait for the slowest pixel of their wave or of
-//                    their workgroup, and a frame of any size fills the chip.  Waves draw tasks in chunks of 64 from
-//                    16 queues (one atomic per 64 tasks) and hand them to their lanes by ballot + mbcnt;
+//                    their workgroup, and a frame of any size fills the chip.  Waves draw tasks in chunks of 64 (the
+//                    first chunk of a wave is static, the rest come from 16 queues: one atomic per 64 tasks) and hand
+//                    them to their lanes by ballot + mbcnt;
 //   merge_kernel   : block sums into the accumulator, in block order (full_buffer.rs:107-125).
 // Which lane runs a task never enters the arithmetic: results equal the one-lane-per-pixel formulation bit for bit.
 // ----------------------------------------------------------------------------------------------------
