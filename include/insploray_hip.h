@@ -156,9 +156,10 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
  * sums are merged into the accumulator in block order.  Blocks are independent until the merge, which is what lets
  * one call fill the GPU.  On a zeroed accumulator a call with spp <= samples_per_block is bit-identical to spp
  * successive reference-style 1-sample calls.
- * IR_SAMPLE_BLOCK_AUTO (0): 128, halved (not below 8) until the launch has at least 8192 x 256 (pixel, block) tasks: a
- * small frame at a low sample count otherwise lasts as long as its longest block runs on one lane (the reference's own
- * headless case, 800x450 at 64 spp: 8-sample blocks render it in 0.4 of the time of one 64-sample block per pixel).  A pure
+ * IR_SAMPLE_BLOCK_AUTO (0): 128, halved until the launch has at least 26000 x 256 (pixel, block) tasks, not below 8 (4 on
+ * frames of fewer than 4096 x 256 pixels): a launch of few long blocks lasts as long as its longest block runs on one lane
+ * (the reference's own headless case, 800x450 at 64 spp: 4-sample blocks render it in 0.37 of the time of one 64-sample
+ * block per pixel; 1080p at 128 spp: 32-sample blocks, 0.8 of the time).  A pure
  * function of the pixels this rank owns — 4096 per 64x64 tile — and spp; ir_get_sample_block returns what a render of
  * that shape would use, so that a caller (or a checker) can reproduce the order of the sums. */
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);

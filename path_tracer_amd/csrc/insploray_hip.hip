@@ -129,16 +129,22 @@ int selected_accel(const ir_context* ctx) {
     return ctx->n_spheres >= kAutoLbvhFrom ? pt::kAccelLbvh : pt::kAccelLinear;
 }
 
-// Samples per accumulation block of a render when ir_set_sample_block selected IR_SAMPLE_BLOCK_AUTO: 128, halved (not
-// below 8) until the launch has at least kAutoMinWorkgroups x 256 (pixel, block) tasks, about five per resident lane.  A
-// small launch lasts as long as its longest task runs on one lane and then drains for about one more task (C1,
-// 800x450x64: 0.82 ms of path kernel with one 64-sample task per pixel, 0.37 ms with four tasks of 16, 0.32 ms with eight
-// of 8; 4-sample tasks are no faster: every task costs a switch).  A pure function of the workgroups-worth of pixels this
-// rank owns and spp, so that a caller (and the oracle in the tests) can reproduce the sum order.
-constexpr uint32_t kAutoMinWorkgroups = 8192;
+// Samples per accumulation block of a render when ir_set_sample_block selected IR_SAMPLE_BLOCK_AUTO: 128, halved until the
+// launch has at least kAutoMinWorkgroups x 256 (pixel, block) tasks, about fifteen per resident lane, but not below 8
+// samples (4 on a frame of fewer than kAutoSmallFrameWorkgroups x 256 pixels).  A launch lasts as long as its tasks keep
+// every lane busy and then drains for about one more task; a task costs a switch.  Measured over 4 frame sizes x 7
+// sample counts x 6 block sizes (tools/auto_block_sweep.py, profiles/r2_auto_block_sweep.txt): the fastest block has
+// 26 000 .. 53 000 workgroups-worth of tasks everywhere (800x450x64: 4; 1080p x 64 / 128 / 256: 16 / 32 / 64; 4K: 64 .. 128),
+// 4-sample blocks only pay on small frames (1080p x 32: 0.70 ms against 0.59 ms with 8), and a single block per pixel (the
+// lane-per-pixel launch, pt_kernels.hip DIRECT) is what the halving ends in when the samples are few.  A pure function
+// of the workgroups-worth of pixels this rank owns and spp, so that a caller (and the oracle in the tests) can reproduce
+// the sum order.
+constexpr uint32_t kAutoMinWorkgroups = 26000;
+constexpr uint32_t kAutoSmallFrameWorkgroups = 4096;
 uint32_t auto_sample_block(uint32_t wgs_per_block, uint32_t spp) {
+    const uint32_t min_block = wgs_per_block < kAutoSmallFrameWorkgroups ? 4u : 8u;
     uint32_t sb = 128;
-    while (sb > 8 && (uint64_t)wgs_per_block * ((spp + sb - 1) / sb) < kAutoMinWorkgroups) sb /= 2;
+    while (sb > min_block && (uint64_t)wgs_per_block * ((spp + sb - 1) / sb) < kAutoMinWorkgroups) sb /= 2;
     return sb;
 }
 

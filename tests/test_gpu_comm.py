@@ -122,23 +122,24 @@ def test_auto_sample_block_and_memory_bounded_blocks(tracer, oracle):
     from path_tracer_amd import _capi, workloads as W
     lib, ctx = _capi.lib, tracer._ctx
     scene = W.scene_s1()
-    # C1's shape: 800x450 = 13x8 tiles = 1664 workgroups-worth of pixels; 64 spp -> blocks of 8 (8 x 1664 >= 8192)
+    # C1's shape: 800x450 = 13x8 tiles = 1664 workgroups-worth of pixels (a small frame: blocks down to 4); 64 spp -> blocks of 4
+    # (16 x 1664 >= 26000); 1080p = 8160: 64 / 128 spp -> 16 / 32, and a launch of few samples ends in one block per pixel
     w, h, spp = 800, 450, 64
     cam = W.default_camera(w, h)
     tracer.set_active_camera(cam)
     tracer.set_sample_block(_capi.IR_SAMPLE_BLOCK_AUTO)
     sb = C.c_uint32()
     _capi.check(ctx, lib.ir_get_sample_block(ctx, w, h, spp, C.byref(sb)))
-    assert sb.value == 8
-    _capi.check(ctx, lib.ir_get_sample_block(ctx, 1920, 1080, 1024, C.byref(sb)))
-    assert sb.value == 128
-    _capi.check(ctx, lib.ir_get_sample_block(ctx, 64, 64, 1, C.byref(sb)))
-    assert sb.value == 8
+    assert sb.value == 4
+    for (w_, h_, spp_, want_sb) in ((1920, 1080, 1024, 128), (1920, 1080, 256, 64), (1920, 1080, 128, 32), (1920, 1080, 64, 16),
+                                    (1920, 1080, 8, 8), (3840, 2160, 64, 128), (800, 450, 256, 16), (800, 450, 128, 8), (64, 64, 1, 4)):
+        _capi.check(ctx, lib.ir_get_sample_block(ctx, w_, h_, spp_, C.byref(sb)))
+        assert sb.value == want_sb, (w_, h_, spp_, sb.value)
     try:
         tracer.render(scene, w, h, False, spp=spp)
         s, c = tracer.get_radiance()
         ocam = oracle.camera_from(cam, w, h)
-        oracle.set_sample_block(8)
+        oracle.set_sample_block(4)
         want, wcnt, _, _ = oracle.render(ocam, scene, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1, threads=16)
         assert np.array_equal(s.view(np.uint32), want.view(np.uint32)) and np.array_equal(c, wcnt)
         # block of 1 at 1080p, 4096 spp
