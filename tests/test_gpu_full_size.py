@@ -173,3 +173,33 @@ def test_c3_full_size_hits_and_sampled_pixels(pta, tracer, oracle):
     for (x, y) in [(960, 540), (200, 900), (1700, 650), (1000, 420), (50, 1000), (1333, 777)]:
         want = _contract_sum(oracle.pixel_samples(ocam, scene, x, y, 256, bounces=8, rr_start=2, seed=SEED, math_mode=1))
         assert s[y, x].tobytes() == want.tobytes(), f"pixel ({x},{y}): {s[y, x]} vs {want}"
+
+
+def test_redraw_loop_at_full_hd_equals_reference_style_sums(pta, tracer, oracle):
+    """The reference's own call pattern at 1080p (frontend/src/app.rs:84-99): render_updated once, then prepare_pixels per
+    redraw, one sample per pixel each (a single-block launch: the lane-per-pixel kernel).  After 8 frames a seeded subset of
+    pixels holds the oracle's samples 0..7 added one by one, the order of 8 successive reference calls; every pixel has 8."""
+    from path_tracer_amd import workloads as W
+    scene = W.scene_s1()
+    cam = W.default_camera(W_, H_)
+    tracer.set_active_camera(cam)
+    tracer.set_integrator(bounces=8, max_compulsory_bounces=2, seed=SEED)
+    tracer.render_updated(scene, W_, H_)
+    for _ in range(7):
+        tracer.prepare_pixels(scene, W_, H_)
+    s, c = tracer.get_radiance()
+    assert (c == 8).all() and (s[..., 3] == np.float32(8.0)).all()
+    ocam = oracle.camera_from(cam, W_, H_)
+    rng = np.random.default_rng(77)
+    pixels = [(int(rng.integers(0, W_)), int(rng.integers(0, H_))) for _ in range(40)]
+    pixels += [(0, 0), (W_ - 1, H_ - 1), (W_ // 2, H_ // 2), (W_ // 2 + 130, H_ // 2 - 40), (960, 300), (1100, 560)]
+    for (x, y) in pixels:
+        exact = oracle.pixel_samples(ocam, scene, x, y, 8, bounces=8, rr_start=2, seed=SEED, math_mode=1)
+        want = np.zeros(4, dtype=np.float32)
+        for v in exact:                                   # one merge per call: frame += (0 + sample)
+            want += np.array([v[0], v[1], v[2], 1.0], dtype=np.float32)
+        assert s[y, x].tobytes() == want.tobytes(), f"pixel ({x},{y}): {s[y, x]} vs {want}"
+    # the same 8 samples in one call are one block summed from zero: the same additions in the same order
+    tracer.render(scene, W_, H_, False, spp=8)
+    s8, c8 = tracer.get_radiance()
+    assert s8.tobytes() == s.tobytes() and c8.tobytes() == c.tobytes()
