@@ -136,7 +136,9 @@ def main():
                     help="N > 1 only. native (default): the library's RCCL step (ir_comm_init / ir_combine_async), overlapped "
                          "with the next render; falls back to torch if RCCL cannot be initialised. torch: torch.distributed "
                          "reduce of the accumulator tensors on the render stream.")
-    ap.add_argument("--sample-block", type=int, default=None, help="ir_set_sample_block (0 = auto); the metric uses the default 128")
+    ap.add_argument("--sample-block", type=int, default=None,
+                    help="ir_set_sample_block; default: IR_SAMPLE_BLOCK_AUTO (0), which is the library default of 128 on C2, C4 and C5 "
+                         "and 64 on C3 (config.sample_block says what the run used)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a box with ONE GPU: every rank uses device 0 and the exchange step goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
@@ -200,8 +202,7 @@ def main():
                      "wavefront": _capi.IR_SCHEDULE_WAVEFRONT}[args.schedule])
     rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
     rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
-    if args.sample_block is not None:
-        rt.set_sample_block(args.sample_block)
+    rt.set_sample_block(args.sample_block if args.sample_block is not None else _capi.IR_SAMPLE_BLOCK_AUTO)
     partition = args.partition or ("tiles" if args.workload == "c4" else "samples")
     if world > 1:
         rt.set_partition(_capi.IR_PARTITION_TILES if partition == "tiles" else _capi.IR_PARTITION_SAMPLES, rank, world)
@@ -381,6 +382,7 @@ def main():
                                                        f"64x64 tiles round-robin x{world}") + (" + RCCL reduce(sum) to rank 0" if partition == "samples" or native is None else " + RCCL gather of owned tiles to rank 0"),
                 "seed": hex(Wk.RNG_SEED),
                 "sky_sampling": args.sky_sampling,
+                "sample_block": rt.get_sample_block(W, H, spp),
             },
             "roofline": {
                 "bound": "valu",
