@@ -1,4 +1,4 @@
-"""Lane activity of the integrators' loops (ir_get_lane_profile) on C2 (scan) or C3 (LBVH): python tools/lane_profile.py [spp] [c2|c3]"""
+"""Lane activity of the integrators' loops (ir_get_lane_profile) on C2 (scan) or C3 (LBVH): python tools/lane_profile.py [spp] [c2|c3] [sample block, 0 = auto]"""
 import os
 import sys
 
@@ -14,6 +14,9 @@ rt = pta.RayTracer(0, 0, device=0)
 rt.set_active_camera(W.default_camera(w, h) if cfg == "c2" else W.camera_s2(w, h))
 rt.set_integrator(bounces=8, max_compulsory_bounces=2, seed=W.RNG_SEED)
 scene = W.scene_s1() if cfg == "c2" else W.scene_s2()
+if len(sys.argv) > 3:
+    rt.set_sample_block(int(sys.argv[3]))
+    print("sample block", rt.get_sample_block(w, h, spp))
 rt.enable_stats()
 rt.render(scene, w, h, False, spp=spp)
 st = rt.get_stats()
