@@ -308,14 +308,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if world == 1:
-        kernel_ms.append(rt.last_kernel_ms())  # the last step's launches (the steps are identical)
-        paths_ms.append(rt.last_paths_kernel_ms())
+        kernel_ms.append(rt.last_kernel_ms())  # the last step's launch sequence (the steps are identical)
+        # the path kernel of every launch of the timed region (the library keeps the last 64 event pairs)
+        n_timed = args.steps * max(1, kernel_ms[-1][1])
+        paths_ms.extend(rt.paths_kernel_history(64)[-n_timed:])
     exchange_info = None
     if world > 1:
         exchange_info = {"how": exchange}
         if native is not None:
-            kernel_ms.append(rt.last_kernel_ms())  # the last step's launches (the steps are identical)
-            paths_ms.append(rt.last_paths_kernel_ms())
+            kernel_ms.append(rt.last_kernel_ms())  # the last step's launch sequence (the steps are identical)
+            n_timed = args.steps * max(1, kernel_ms[-1][1])
+            paths_ms.extend(rt.paths_kernel_history(64)[-n_timed:])
             exchange_info["last_exchange_ms"] = native.last_ms()
             exchange_info["bytes_per_rank"] = (int(_capi.lib.ir_tile_payload_bytes(W, H, rank, world)) if partition == "tiles"
                                                else W * H * 20)
@@ -400,6 +403,7 @@ def main():
                 "pmc_source": pmc_source,
                 "kernel": "paths_lbvh_kernel<false, false>" if lbvh else "paths_kernel<false, false>",
                 "avg_launch_ms": avg_launch_ms,
+                "launches_averaged": len(paths_ms),
                 "avg_launch_sequence_ms": avg_sequence_ms,
                 "launches_per_step": launches_per_step,
                 "loop_lane_utilisation": prof[list(prof)[0]][1] / max(1, 64 * prof[list(prof)[0]][0]),

@@ -279,6 +279,10 @@ double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches);
 /* Device time of the path kernel alone (the persistent kernel that runs every sample block of every pixel whose primary
  * ray hits something; the dominant kernel) in the LAST launch of the last render, ms; 0 when that render launched none. */
 double ir_last_paths_kernel_ms(const ir_context* ctx);
+/* The same for the last launches of this context, oldest first: up to 64 are kept (a ring of event pairs), so a caller
+ * that enqueues renders with ir_render_async and waits once can still average over all of them.  *out_n = how many were
+ * written (<= max_n).  Waits for the last launch. */
+int ir_get_paths_kernel_history(const ir_context* ctx, double* out_ms, uint32_t max_n, uint32_t* out_n);
 /* Samples per pixel accumulated by this context since the last reset. */
 uint32_t ir_samples_accumulated(const ir_context* ctx);
 /* Checkpoint restore: after ir_set_radiance with a stored accumulator, tell the context how many samples per pixel

@@ -16,6 +16,38 @@ if not os.path.exists(LIB_PATH):
         "path_tracer_amd has no CPU fallback."
     )
 
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own copy (torch/lib/libamdhip64.so + libhsa-runtime64.so)
+    and cannot be told to use another; a second copy in the same process finds no GPU (measured: this library on
+    /opt/rocm's runtime first, `import torch` afterwards -> "No HIP GPUs are available"; tools/load_order_probe.py).  The
+    other order works: the dynamic linker hands torch's already-loaded copy (same SONAME) to this library.  So when torch
+    is installed but not imported yet, and no HIP runtime is mapped yet (a profiler's preload may have brought one), load
+    torch's copy first.  IR_SYSTEM_HIP_RUNTIME=1 keeps the system runtime (then import torch first, or not at all)."""
+    import importlib.util
+    import sys
+    if os.environ.get("IR_SYSTEM_HIP_RUNTIME") == "1" or "torch" in sys.modules:
+        return None
+    try:
+        with open("/proc/self/maps") as f:
+            if any("libamdhip64" in line for line in f):
+                return None
+        spec = importlib.util.find_spec("torch")
+    except (OSError, ImportError, ValueError):
+        return None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path)
+    except OSError:
+        return None
+
+
+_torch_hip_runtime = _share_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 IR_OK = 0
@@ -88,6 +120,7 @@ PROTOTYPES = {
     "ir_last_render_seconds": (C.c_double, [ctx_p]),
     "ir_last_kernel_ms": (C.c_double, [ctx_p, c_u32_p]),
     "ir_last_paths_kernel_ms": (C.c_double, [ctx_p]),
+    "ir_get_paths_kernel_history": (C.c_int, [ctx_p, C.POINTER(C.c_double), C.c_uint32, c_u32_p]),
     "ir_samples_accumulated": (C.c_uint32, [ctx_p]),
     "ir_set_samples_accumulated": (C.c_int, [ctx_p, C.c_uint32]),
     "ir_device_radiance": (C.c_void_p, [ctx_p]),

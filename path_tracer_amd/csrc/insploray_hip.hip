@@ -334,8 +334,10 @@ int ir_create(ir_context** out_ctx, int device) {
     ctx->stream = ctx->own_stream;
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipEventCreate(&ctx->ev_p0)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipEventCreate(&ctx->ev_p1)) != hipSuccess) return bail("hipEventCreate", e);
+    for (uint32_t k = 0; k < ir_context::kTimerRing; ++k) {
+        if ((e = hipEventCreate(&ctx->ev_p0[k])) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreate(&ctx->ev_p1[k])) != hipSuccess) return bail("hipEventCreate", e);
+    }
     if (init_noalloc_scratch(device, &e) != IR_OK) return bail("hipGetSymbolAddress(static scratch)", e);
     if ((e = pt::init_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
     if ((e = pt::init_wavefront_kernels()) != hipSuccess) return bail("kernel attribute setup", e);
@@ -360,8 +362,10 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_sky_marginal_guide); release(ctx->d_sky_cond_guide);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->ev_p0) (void)hipEventDestroy(ctx->ev_p0);
-    if (ctx->ev_p1) (void)hipEventDestroy(ctx->ev_p1);
+    for (uint32_t k = 0; k < ir_context::kTimerRing; ++k) {
+        if (ctx->ev_p0[k]) (void)hipEventDestroy(ctx->ev_p0[k]);
+        if (ctx->ev_p1[k]) (void)hipEventDestroy(ctx->ev_p1[k]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -792,12 +796,16 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
             a.task_counters_next = pairs + (ctx->launch_parity ^ 1u) * pt::kTaskCounterPairStride;
             ctx->launch_parity ^= 1u;
         }
-        const hipError_t le = pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream, ctx->ev_p0, ctx->ev_p1);
+        const uint32_t timer = (uint32_t)(ctx->launches_timed % ir_context::kTimerRing);
+        const hipError_t le = pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream, ctx->ev_p0[timer], ctx->ev_p1[timer]);
         if (le != hipSuccess) {
             ctx->task_counters_clean = false;  // whatever ran may have left the counters anywhere
             return fail(ctx, IR_EDEVICE, "%s: launch failed: %s", who, hipGetErrorString(le));
         }
-        ctx->paths_timed = true;
+        if (owned_wgs != 0) {  // (a rank that owns no tile recorded nothing)
+            ctx->paths_timed = true;
+            ctx->launches_timed++;
+        }
         done += now;
         ctx->last_launches++;
     }
@@ -981,12 +989,32 @@ double ir_last_kernel_ms(const ir_context* ctx, uint32_t* n_launches) {
 }
 
 double ir_last_paths_kernel_ms(const ir_context* ctx) {
-    if (!ctx || !ctx->paths_timed) return 0.0;
+    if (!ctx || !ctx->paths_timed || ctx->launches_timed == 0) return 0.0;
     if (hipSetDevice(ctx->device) != hipSuccess) return 0.0;
-    if (hipEventSynchronize(ctx->ev_p1) != hipSuccess) return 0.0;
+    const uint32_t k = (uint32_t)((ctx->launches_timed - 1) % ir_context::kTimerRing);
+    if (hipEventSynchronize(ctx->ev_p1[k]) != hipSuccess) return 0.0;
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev_p0, ctx->ev_p1) != hipSuccess) return 0.0;
+    if (hipEventElapsedTime(&ms, ctx->ev_p0[k], ctx->ev_p1[k]) != hipSuccess) return 0.0;
     return (double)ms;
+}
+
+int ir_get_paths_kernel_history(const ir_context* ctx, double* out_ms, uint32_t max_n, uint32_t* out_n) {
+    if (!ctx) return IR_EINVAL;
+    if (!out_n || (!out_ms && max_n)) return fail(ctx, IR_EINVAL, "ir_get_paths_kernel_history: NULL");
+    uint64_t n = ctx->launches_timed < ir_context::kTimerRing ? ctx->launches_timed : ir_context::kTimerRing;
+    if (n > max_n) n = max_n;
+    *out_n = (uint32_t)n;
+    if (n == 0) return IR_OK;
+    IR_TRY(use_device(ctx));
+    const uint64_t first = ctx->launches_timed - n;
+    IR_HIP(ctx, hipEventSynchronize(ctx->ev_p1[(ctx->launches_timed - 1) % ir_context::kTimerRing]));
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t k = (uint32_t)((first + i) % ir_context::kTimerRing);
+        float ms = 0.0f;
+        IR_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_p0[k], ctx->ev_p1[k]));
+        out_ms[i] = (double)ms;
+    }
+    return IR_OK;
 }
 
 uint32_t ir_samples_accumulated(const ir_context* ctx) { return ctx ? ctx->samples_done : 0; }

@@ -27,8 +27,12 @@ struct ir_context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around all launches of a render call
-    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // around the path kernel of its last launch
-    bool paths_timed = false;
+    // around the path kernel of each launch: a ring of event pairs, so that a caller that enqueues many renders without
+    // waiting (bench.py's timed region) can still read every launch's duration afterwards (ir_get_paths_kernel_history)
+    static constexpr uint32_t kTimerRing = 64;
+    hipEvent_t ev_p0[kTimerRing] = {}, ev_p1[kTimerRing] = {};
+    uint64_t launches_timed = 0;  // launches whose path kernel was bracketed since the context was created
+    bool paths_timed = false;     // the last render launched a path kernel
     mutable std::string err;
 
     // scene (host copies kept so that the per-sphere shading table can be rebuilt when either side changes)

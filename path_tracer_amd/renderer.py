@@ -212,6 +212,13 @@ class RayTracer:
         """Device time of the path kernel of the last launch (ir_last_paths_kernel_ms)."""
         return float(_capi.lib.ir_last_paths_kernel_ms(self._ctx))
 
+    def paths_kernel_history(self, n=64):
+        """Device time of the path kernel of the last (up to 64) launches, oldest first (ir_get_paths_kernel_history)."""
+        out = (C.c_double * int(n))()
+        got = C.c_uint32()
+        _capi.check(self._ctx, _capi.lib.ir_get_paths_kernel_history(self._ctx, out, int(n), C.byref(got)))
+        return [float(out[i]) for i in range(got.value)]
+
     def samples_accumulated(self):
         return int(_capi.lib.ir_samples_accumulated(self._ctx))
 

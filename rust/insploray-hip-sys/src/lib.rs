@@ -69,6 +69,7 @@ extern "C" {
     pub fn ir_last_render_seconds(ctx: *const ir_context) -> c_double;
     pub fn ir_last_kernel_ms(ctx: *const ir_context, n_launches: *mut u32) -> c_double;
     pub fn ir_last_paths_kernel_ms(ctx: *const ir_context) -> c_double;
+    pub fn ir_get_paths_kernel_history(ctx: *const ir_context, out_ms: *mut c_double, max_n: u32, out_n: *mut u32) -> c_int;
     pub fn ir_samples_accumulated(ctx: *const ir_context) -> u32;
     pub fn ir_set_samples_accumulated(ctx: *mut ir_context, samples: u32) -> c_int;
     pub fn ir_device_radiance(ctx: *mut ir_context) -> *mut c_void;

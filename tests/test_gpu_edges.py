@@ -235,6 +235,20 @@ def test_launch_timers_and_lane_profile(pta, tracer):
     seq_ms, launches = tracer.last_kernel_ms()
     paths_ms = tracer.last_paths_kernel_ms()
     assert launches == 1 and 0.0 < paths_ms <= seq_ms < 1000.0
+    # renders enqueued without waiting: every launch's path kernel can still be read afterwards, oldest first
+    before = len(tracer.paths_kernel_history())
+    for _ in range(5):
+        tracer.render(scene, w, h, True, spp=spp, blocking=False)
+    tracer.synchronize()
+    hist = tracer.paths_kernel_history()
+    assert len(hist) == min(64, before + 5) and all(0.0 < t < 1000.0 for t in hist[-5:])
+    assert hist[-1] == tracer.last_paths_kernel_ms()
+    assert tracer.paths_kernel_history(3) == hist[-3:]
+    for _ in range(70):                                # more launches than the ring holds
+        tracer.render(scene, 64, 36, True, spp=1, blocking=False)
+    tracer.synchronize()
+    hist = tracer.paths_kernel_history()
+    assert len(hist) == 64 and all(0.0 < t < 1000.0 for t in hist)
     with pytest.raises(pta.InsplorayError):
         tracer.get_lane_profile()  # no statistics render yet
     tracer.enable_stats()

@@ -5,6 +5,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (at collection time: PyTorch-ROCm's bundled HIP runtime has to be the process's first, _capi.py)
 
 pytestmark = pytest.mark.gpu
 
