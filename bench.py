@@ -113,8 +113,9 @@ def self_launch(argv, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    # (three warm-up steps = 38 ms on C2: the shader clock is still ramping during the first two launches of a process)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (the metric is quoted at 1024)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
