@@ -63,3 +63,17 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"oracle_lib|liboracle|oracle/|import oracle|orc_", txt):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """PyTorch-ROCm bundles its own HIP runtime; two copies in one process leave the second without a GPU.  _capi.py loads
+    torch's copy first when torch is installed, so the library and a later `import torch` share one (no GPU needed to see it)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import path_tracer_amd._capi as c; import torch\n"
+            "paths = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(len(paths), paths)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "IR_SYSTEM_HIP_RUNTIME"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
