@@ -834,12 +834,15 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
                                                       uint32_t* __restrict__ argb, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // the weight channel of a rendered pixel is its sample count (every sample adds 1): the mean is exactly 1 and the
+    // byte is the same for all of them; one powf per thread instead of one per pixel
+    const uint32_t alpha_of_one = to_byte(tone(1.0f, 1.0f));
     for (; i < n; i += stride) {
         const float4 s = sum[i];
         const uint32_t c = counts[i];
         const float nf = (float)(c > 1u ? c : 1u);
-        argb[i] = (to_byte(tone(s.w, nf)) << 24) | (to_byte(tone(s.x, nf)) << 16) | (to_byte(tone(s.y, nf)) << 8) |
-                  to_byte(tone(s.z, nf));
+        const uint32_t alpha = (s.w == nf) ? alpha_of_one : to_byte(tone(s.w, nf));
+        argb[i] = (alpha << 24) | (to_byte(tone(s.x, nf)) << 16) | (to_byte(tone(s.y, nf)) << 8) | to_byte(tone(s.z, nf));
     }
 }
 
