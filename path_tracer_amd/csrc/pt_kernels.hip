@@ -827,6 +827,8 @@ __device__ __forceinline__ float tone(float sum, float n) {
     a = a / (a + 1.0f);
     // a^(1/2.2) through the hardware log2 / exp2 (1 ulp each): the result becomes a byte, at most 1 LSB from libm's powf
     // (the bar of tests/test_gpu_parity.py::test_resolve_argb_within_one_lsb); the library powf was 2/3 of this kernel
+    // (powf(-inf, 1/2.2) is +inf — a mean of exactly -1 — where log2 would give NaN; every other negative is NaN in both)
+    a = (a == -__builtin_inff()) ? __builtin_inff() : a;
     a = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * (1.0f / 2.2f));
     a = (a > 0.0f) ? a : 0.0f;  // clamp(0,1); NaN -> 0 like SSE max/min
     a = (a < 1.0f) ? a : 1.0f;

@@ -20,6 +20,12 @@ sums = np.zeros((h, w, 4), dtype=np.float32)
 sums[..., :3] = mean.reshape(h, w, 3) * counts[..., None]
 sums[..., 3] = counts
 sums[0, 0] = (np.inf, np.nan, -1.0, 7.0)
+# the corners of powf: a mean of exactly -1 (Reinhard -> -inf -> +inf), other negatives (NaN -> 0), -0, denormals, huge
+counts[0, 1:8] = 1
+sums[0, 1] = (-1.0, -0.5, -2.0, 1.0)
+sums[0, 2] = (-0.0, 1e-40, 3e38, 1.0)
+sums[0, 3] = (-np.inf, 1e-45, 1.1754944e-38, 1.0)
+sums[0, 4] = (-1.0000001, -0.99999994, 0.0, 1.0)
 rt.set_radiance(sums, counts)
 out = rt.get_output().copy().reshape(h, w)
 ref = oracle.resolve_argb(sums, counts).reshape(h, w)
