@@ -243,6 +243,38 @@ def test_resolve_argb_within_one_lsb(pta, tracer, oracle):
     assert ((out >> 24) == 0xBA).all()  # alpha goes through Reinhard + gamma (full_buffer.rs:53-62)
 
 
+def test_resolve_corners_and_wide_range(pta, tracer, oracle):
+    """The tone map's a^(1/2.2) runs on the hardware log2/exp2: against the oracle (libm powf) over 18 decades of radiance and
+    at powf's corners — a mean of exactly -1 (Reinhard gives -inf, powf +inf, the byte 255), other negatives and NaN (0),
+    -0, denormals, infinities — never more than 1 LSB, and exact at the corners."""
+    from path_tracer_amd import workloads as W
+    w, h = 256, 128
+    tracer.set_active_camera(W.default_camera(w, h))
+    tracer.render(W.scene_s1(skybox=None), w, h, False, spp=0)
+    rng = np.random.default_rng(5)
+    counts = rng.integers(1, 5000, (h, w)).astype(np.uint32)
+    mean = np.exp(rng.uniform(np.log(1e-12), np.log(1e6), (h, w, 3))).astype(np.float32)
+    sums = np.zeros((h, w, 4), dtype=np.float32)
+    sums[..., :3] = mean * counts[..., None]
+    sums[..., 3] = counts
+    counts[0, :8] = 1
+    sums[0, 0] = (np.inf, np.nan, -1.0, 1.0)
+    sums[0, 1] = (-1.0, -0.5, -2.0, 1.0)
+    sums[0, 2] = (-0.0, 1e-40, 3e38, 1.0)
+    sums[0, 3] = (-np.inf, 1e-45, 1.1754944e-38, 1.0)
+    sums[0, 4] = (-1.0000001, -0.99999994, 0.0, 1.0)
+    sums[0, 5:8] = 0.0
+    sums[0, 5:8, 3] = 1.0
+    tracer.set_radiance(sums, counts)
+    out = tracer.get_output().copy().reshape(h, w)
+    ref = oracle.resolve_argb(sums, counts).reshape(h, w)
+    for shift in (0, 8, 16, 24):
+        d = ((out >> shift) & 0xFF).astype(np.int32) - ((ref >> shift) & 0xFF).astype(np.int32)
+        assert np.abs(d).max() <= 1 and (d != 0).mean() < 1e-3
+    assert (out[0, :8] == ref[0, :8]).all(), ([hex(int(v)) for v in out[0, :8]], [hex(int(v)) for v in ref[0, :8]])
+    assert (out[0, 1] >> 16) & 0xFF == 255 and (out[0, 1] >> 8) & 0xFF == 0      # mean -1 -> 255; mean -0.5 -> NaN -> 0
+
+
 def test_stats_match_oracle(pta, tracer, oracle):
     from path_tracer_amd import workloads as W
     w, h, spp = 128, 72, 8
