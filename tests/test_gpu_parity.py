@@ -201,7 +201,7 @@ def test_accumulate_equals_successive_calls(pta, tracer, oracle):
     assert tracer.get_current_size() == [w + 1, h]
 
 
-@pytest.mark.parametrize("block,spp", [(64, 200), (16, 40), (1, 5), (4096, 70)])
+@pytest.mark.parametrize("block,spp", [(64, 200), (16, 40), (1, 5), (4096, 70), (2, 45), (3, 50)])  # (the last two: 23 + 12 and 17 + 9 blocks, merge_kernel's batches of eight and their remainders)
 def test_sample_blocks_match_oracle(pta, tracer, oracle, block, spp):
     """A multi-sample call = consecutive blocks, each summed from zero (the reference's TileAccumulator) and merged in
     order (merge_tile); blocks run as independent workgroups on the GPU, the oracle restates the same sum."""
