@@ -316,7 +316,7 @@ int ir_get_lane_profile(ir_context* ctx, uint64_t out8[8]);
  * f32 sqrt / divide expansions by short sequences that return the same correctly rounded bits; this runs, on the
  * context's GPU, the exhaustive (all 2^32 inputs) and randomised (2^log2_random_samples cases) comparisons against
  * the IEEE expansions and fills 10 mismatch counters, all of which must be 0:
- *   [0] sqrt  [1] 1/sqrt (two roundings)  [2] 1/x  [3] x/PI  [4] x/2PI  [5] (x-1)/(x+1) of the atan kernel
+ *   [0] sqrt  [1] 1/sqrt (two roundings)  [2] 1/x  [3] x/PI  [4] x/2PI  [5] min/max of atan2's one divide
  *   [6] a/b pairs  [7] (brdf*cos)/(cos/PI) weights  [8] contribution/p  [9] one-divide closest-hit scan vs literal scan */
 int ir_selftest_exact_math(ir_context* ctx, uint64_t* out_mismatches, uint32_t n_out, uint32_t log2_random_samples);
 

@@ -72,7 +72,7 @@ inline V3 normalize(V3 a) { return a * (1.0f / std::sqrt(dot(a, a))); }
 // ---------------------------------------------------------------------------------------------
 // math_mode 1: restatement of the device polynomial transcendentals (path_tracer_amd/csrc/pt_math.h).
 // Plain f32 + - * / only, no FMA: bit-reproducible between x86 SSE and gfx950 VALU.
-// Coefficients are the classic single-precision Cephes minimax sets.
+// sin/cos and acos use the classic single-precision Cephes minimax sets; atan2 is a one-divide form fitted in pt_device.h.
 // ---------------------------------------------------------------------------------------------
 inline void poly_sincos(float x, float* s_out, float* c_out) {
     // valid for 0 <= x < 8*pi/4 .. (we only ever pass phi in [0, 2*pi])
@@ -105,33 +105,25 @@ inline float poly_acos(float x) {  // x in [-1,1]; NaN propagates
     if (x < -0.5f) return kPi - 2.0f * poly_asin_core(std::sqrt(0.5f * (1.0f + x)));
     return PIO2 - poly_asin_core(x);
 }
-inline float poly_atan_pos(float x) {  // x >= 0
-    const float PIO2 = 1.5707963267948966f, PIO4 = 0.7853981633974483f;
-    float y;
-    if (x > 2.414213562373095f) {
-        y = PIO2;
-        x = -(1.0f / x);
-    } else if (x > 0.4142135623730950f) {
-        y = PIO4;
-        x = (x - 1.0f) / (x + 1.0f);
-    } else {
-        y = 0.0f;
-    }
-    float z = x * x;
-    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
-    return y;
-}
 inline float poly_atan2(float y, float x) {
-    // quadrant logic on magnitudes; the sign of zero is ignored (x == 0 && y == 0 -> 0)
-    float ax = std::fabs(x), ay = std::fabs(y);
-    float a;
-    if (ax == 0.0f && ay == 0.0f) {
-        a = 0.0f;
-    } else if (ax == 0.0f) {
-        a = 1.5707963267948966f;
-    } else {
-        a = poly_atan_pos(ay / ax);
-    }
+    // one divide: q = min(|x|, |y|) / max(|x|, |y|), atan(q) = q * P(q * q) with the degree-7 P of the device code
+    // (pt_device.h atan2_poly: fitted there, 1.7e-7 rad), then the octant; the sign of zero is ignored (0, 0 -> 0)
+    const float ax = std::fabs(x), ay = std::fabs(y);
+    const bool steep = ay > ax;
+    const float mx = steep ? ay : ax, mn = steep ? ax : ay;
+    const float q = mn / mx;
+    const float z = q * q;
+    float p = -0.004668773151934147f;
+    p = p * z + 0.02416618913412094f;
+    p = p * z - 0.0593671016395092f;
+    p = p * z + 0.09906096756458282f;
+    p = p * z - 0.14016585052013397f;
+    p = p * z + 0.19969235360622406f;
+    p = p * z - 0.33331960439682007f;
+    p = p * z + 0.9999998807907104f;
+    float a = p * q;
+    if (mx == 0.0f) a = 0.0f;
+    if (steep) a = 1.5707963267948966f - a;
     if (x < 0.0f) a = kPi - a;
     if (y < 0.0f) a = -a;
     return a;

@@ -177,42 +177,36 @@ PT_DEV float acos_poly(float x) {
     const float two_p = 2.0f * p;
     return big ? ((x > 0.5f) ? two_p : kPi - two_p) : PIO2 - p;
 }
-// atan on [0, inf): argument reduction to num/den (x > tan(3pi/8): -1/x; x > tan(pi/8): (x-1)/(x+1); else x/1,
-// which is exact), one divide for all three ranges, one polynomial.
-PT_DEV float atan_pos(float x) {  // x >= 0
-    const float PIO2 = 1.5707963267948966f, PIO4 = 0.7853981633974483f;
-    const bool hi = x > 2.414213562373095f, mid = !hi && (x > 0.4142135623730950f);
-    const float y0 = hi ? PIO2 : (mid ? PIO4 : 0.0f);
+// atan2 with ONE divide: q = min(|x|, |y|) / max(|x|, |y|) in [0, 1], atan(q) = q * P(q^2) with a degree-7 P fitted here
+// (Chebyshev interpolation of atan(sqrt z) / sqrt z on [0, 1]; largest error of the f32 evaluation 1.7e-7 rad, the
+// classic three-range reduction it replaces had two divides and the same error), then the octant: pi/2 - a when
+// |y| > |x|, pi - a for x < 0, sign of y.  x == y == 0 gives 0, the sign of zero is ignored.  Plain * + - / in this
+// order, so that a CPU restatement gives the same bits.
+PT_DEV float atan2_poly(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const bool steep = ay > ax;
+    const float mx = steep ? ay : ax, mn = steep ? ax : ay;
     float q;
 #if PT_FAST_MATH
-    const float num = hi ? -1.0f : (mid ? x - 1.0f : x);
-    const float den = hi ? x : (mid ? x + 1.0f : 1.0f);
-    // den in [1, 2^64), num == +0 or |num| >= 2^-100 (x/1 is exact for ANY x: q0 = x, residuals 0)
-    if (__builtin_expect(wave_all(den < 1.8446744e+19f), 1)) q = div_seq(num, den, rcp_seq(den)); else
+    // |x|, |y| of a (normalised) direction: mx in [2^-63, 2), mn == +0 or in [2^-36, 2) keeps the quotient in
+    // [2^-37, 1]: div_seq's domain.  Anything else takes the IEEE divide, wave by wave.
+    if (__builtin_expect(wave_all(in_pow2_range<64, 128>(mx) && (f32_bits(mn) == 0u || in_pow2_range<91, 128>(mn))), 1))
+        q = div_seq(mn, mx, rcp_seq(mx));
+    else
 #endif
-    q = hi ? -(1.0f / x) : (mid ? (x - 1.0f) / (x + 1.0f) : x);
+        q = mn / mx;
     const float z = q * q;
-    return y0 + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * q + q);
-}
-PT_DEV float atan2_poly(float y, float x) {
-    float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    float a;
-    if (ax == 0.0f && ay == 0.0f) {
-        a = 0.0f;
-    } else if (ax == 0.0f) {
-        a = 1.5707963267948966f;
-    } else {
-        float q;
-#if PT_FAST_MATH
-        // |x|, |y| of a (normalised) direction: ax in [2^-63, 2), ay == +0 or in [2^-36, 2) keeps the quotient in
-        // [2^-37, 2^64): div_seq's domain.  Anything else takes the IEEE divide, wave by wave.
-        if (__builtin_expect(wave_all(in_pow2_range<64, 128>(ax) && (f32_bits(ay) == 0u || in_pow2_range<91, 128>(ay))), 1))
-            q = div_seq(ay, ax, rcp_seq(ax));
-        else
-#endif
-            q = ay / ax;
-        a = atan_pos(q);
-    }
+    float p = -0.004668773151934147f;
+    p = p * z + 0.02416618913412094f;
+    p = p * z - 0.0593671016395092f;
+    p = p * z + 0.09906096756458282f;
+    p = p * z - 0.14016585052013397f;
+    p = p * z + 0.19969235360622406f;
+    p = p * z - 0.33331960439682007f;
+    p = p * z + 0.9999998807907104f;
+    float a = p * q;
+    if (mx == 0.0f) a = 0.0f;  // 0 / 0
+    if (steep) a = 1.5707963267948966f - a;
     if (x < 0.0f) a = kPi - a;
     if (y < 0.0f) a = -a;
     return a;

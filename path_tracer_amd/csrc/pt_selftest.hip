@@ -28,9 +28,13 @@ __global__ __launch_bounds__(256) void selftest_unary(unsigned long long* bad) {
             miss[3] += !same(div_const_seq<0>(x), x / kPi);
             miss[4] += !same(div_const_seq<1>(x), x / kTwoPi);
         }
-        if (x > 0.4142135623730950f && !(x > 2.414213562373095f)) {  // atan_pos middle branch
-            const float den = x + 1.0f;
-            miss[5] += !same(div_seq(x - 1.0f, den, rcp_seq(den)), (x - 1.0f) / (x + 1.0f));
+        {   // atan2_poly's quotient: the smaller magnitude over the larger one, every |x| against a hashed partner
+            const uint32_t k = mix32(u);
+            const float other = as_f((k & 0x007fffffu) | ((64u + (k >> 23) % 64u) << 23));  // [2^-63, 2)
+            const bool steep = other > ax;
+            const float mx = steep ? other : ax, mn = steep ? ax : other;
+            if (in_pow2_range<64, 128>(mx) && (f32_bits(mn) == 0u || in_pow2_range<91, 128>(mn)))
+                miss[5] += !same(div_seq(mn, mx, rcp_seq(mx)), mn / mx);
         }
     }
     for (int k = 0; k < 6; ++k)
