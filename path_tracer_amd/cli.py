@@ -82,6 +82,9 @@ def main(argv=None):
     ap.add_argument("--sky-sampling", choices=["bsdf", "mis"], default="bsdf",
                     help="bsdf: the reference's estimator; mis: sky importance sampling (extension)")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
+    ap.add_argument("--sample-block", default="128",
+                    help="samples per accumulation block (ir_set_sample_block): a number, or 'auto' = sized for throughput "
+                         "(the order of the sums follows it; 128 is the library default)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", help="image to write: .exr (linear mean radiance), .png or .ppm (resolved frame)")
     ap.add_argument("--checkpoint", help="write the accumulator (.npz) after rendering")
@@ -97,6 +100,7 @@ def main(argv=None):
         rt.set_sky_filter(_capi.IR_SKY_BILINEAR if args.sky_filter == "bilinear" else _capi.IR_SKY_NEAREST)
         rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
         rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
+        rt.set_sample_block(_capi.IR_SAMPLE_BLOCK_AUTO if args.sample_block == "auto" else int(args.sample_block))
         resumed = 0
         if args.resume:
             ck = np.load(args.resume)
@@ -124,6 +128,7 @@ def main(argv=None):
         print(json.dumps({
             "scene": args.scene, "width": w, "height": h, "spp": args.spp, "samples_total": resumed + args.spp,
             "bounces": args.bounces, "rr_start": args.rr_start, "accel": rt.get_accel_info(),
+            "sample_block": rt.get_sample_block(w, h, args.spp),
             "render_seconds": wall, "kernel_ms": kernel_ms, "launches": launches,
             "msamples_per_s": w * h * args.spp / max(kernel_ms, 1e-9) / 1e3, "out": args.out,
         }))

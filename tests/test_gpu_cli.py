@@ -42,6 +42,11 @@ def test_cli_checkpoint_resume_bit_identical(tmp_path, capsys):
     finally:
         rt.close()
     assert np.array_equal(b["sums"].view(np.uint32), two_calls.view(np.uint32)) and np.array_equal(b["counts"], cnt)
+    # --sample-block auto: the metrics line says which block size the render used (a small frame at 64 spp: 4)
+    assert cli.main(common + ["--spp", "64", "--sample-block", "auto"]) == 0
+    assert cli.main(common + ["--spp", "64"]) == 0
+    auto, default = [json.loads(x) for x in capsys.readouterr().out.strip().splitlines()][-2:]
+    assert auto["sample_block"] == 4 and default["sample_block"] == 128
     # ... and the same 8 samples as the single 8-sample call, up to the order of the f32 additions
     assert np.array_equal(a["counts"], b["counts"]) and np.allclose(a["sums"], b["sums"], rtol=1e-5, atol=1e-6)
     assert not np.array_equal(a["sums"][..., :3], np.load(tmp_path / "half.npz")["sums"][..., :3])
