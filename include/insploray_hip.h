@@ -121,6 +121,13 @@ int ir_get_accel_build_info(ir_context* ctx, int* out_builder, double* out_secon
  * may be NULL.  IR_ESTATE when the scene is rendered with the linear scan. */
 int ir_download_accel(ir_context* ctx, void* wide_nodes, uint32_t n_nodes, float* leaf_spheres, int32_t* leaf_index,
                       uint32_t n_spheres);
+/* The rest of the LBVH (for inspection and tests): the climb records that let a bounce ray start its traversal at the
+ * leaf of the sphere it leaves (layout in path_tracer_amd/csrc/lbvh.h "Climb records": n_records = node count +
+ * n_spheres entries of 64 bytes, those of the inner nodes first, then those of the leaves by first leaf position) and,
+ * per sphere in original order, two int32: the sphere's leaf reference and that leaf's record (0x7fffffff: none).  The
+ * reference has no acceleration structure (integrator.rs:106-127 is the scan these arrays prune).  Either pointer may be
+ * NULL.  IR_ESTATE when the scene is rendered with the linear scan. */
+int ir_download_accel_climb(ir_context* ctx, void* climb_records, uint32_t n_records, int32_t* sphere_start, uint32_t n_spheres);
 
 /* -------------------------------------------------------------------------------------------------
  * Camera.  `dyn Camera` (cameras/mod.rs:7-17) is host code; PinholeCamera is the fast path.

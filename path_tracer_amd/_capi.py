@@ -87,6 +87,7 @@ PROTOTYPES = {
     "ir_set_accel_build": (C.c_int, [ctx_p, C.c_int]),
     "ir_get_accel_build_info": (C.c_int, [ctx_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "ir_download_accel": (C.c_int, [ctx_p, C.c_void_p, C.c_uint32, c_float_p, c_i32_p, C.c_uint32]),
+    "ir_download_accel_climb": (C.c_int, [ctx_p, C.c_void_p, C.c_uint32, c_i32_p, C.c_uint32]),
     "ir_set_pinhole": (C.c_int, [ctx_p, c_float_p, c_float_p, C.c_float, C.c_float]),
     "ir_set_primary_rays": (C.c_int, [ctx_p, c_float_p, C.c_uint32, C.c_uint32]),
     "ir_pinhole_compute": (C.c_int, [c_float_p, c_float_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32,

@@ -184,7 +184,8 @@ int build_bvh_host(ir_context* ctx) {
     IR_TRY(upload(ctx, ctx->d_bvh_nodes, t.wide.data(), t.wide.size() * sizeof(pt::WideNode)));
     IR_TRY(upload(ctx, ctx->d_bvh_spheres, t.leaf_spheres.data(), t.leaf_spheres.size() * sizeof(float)));
     IR_TRY(upload(ctx, ctx->d_bvh_index, t.leaf_index.data(), t.leaf_index.size() * sizeof(int32_t)));
-    ctx->bvh_nodes = (uint32_t)t.wide.size();
+    IR_TRY(upload(ctx, ctx->d_bvh_start, t.sphere_start.data(), t.sphere_start.size() * sizeof(int32_t)));
+    ctx->bvh_nodes = t.n_inner;
     ctx->bvh_depth = t.max_depth;
     ctx->bvh_stack = t.stack_depth;
     ctx->bvh_built_by = IR_BUILD_HOST;
@@ -200,13 +201,18 @@ int build_bvh_device(ir_context* ctx, bool* too_deep) {
     IR_TRY(ensure(ctx, ctx->d_bvh_scratch, pt::lbvh_build_scratch_bytes(n)));
     IR_TRY(ensure(ctx, ctx->d_bvh_spheres, (size_t)n * 16));
     IR_TRY(ensure(ctx, ctx->d_bvh_index, (size_t)n * 4));
-    IR_TRY(ensure(ctx, ctx->d_bvh_nodes, (size_t)(n - 1) * sizeof(pt::WideNode)));
+    // room for the most records a tree of n spheres can have: n - 1 wide nodes, as many climb records of inner nodes, n of leaves
+    const size_t records_bytes = (2 * (size_t)(n - 1) + n) * sizeof(pt::WideNode);
+    IR_TRY(ensure(ctx, ctx->d_bvh_nodes, records_bytes));
+    IR_TRY(ensure(ctx, ctx->d_bvh_start, (size_t)n * 8));
     pt::LbvhDeviceTree tree;
     const hipError_t e = pt::lbvh_build_device((const float4*)ctx->d_spheres.p, n, ctx->d_bvh_scratch.p, ctx->d_bvh_scratch.bytes,
                                                (float4*)ctx->d_bvh_spheres.p, (int*)ctx->d_bvh_index.p, &tree, refit, ctx->stream);
     if (e != hipSuccess)
         return fail(ctx, IR_EDEVICE, "device LBVH build of %u spheres, stage %s: %s", n, tree.failed_stage, hipGetErrorString(e));
-    IR_HIP(ctx, pt::lbvh_emit_device((const float4*)ctx->d_spheres.p, n, tree, (float4*)ctx->d_bvh_nodes.p, ctx->stream));
+    // (record slots no node owns stay zero, as in the host build)
+    IR_HIP(ctx, hipMemsetAsync(ctx->d_bvh_nodes.p, 0, records_bytes, ctx->stream));
+    IR_HIP(ctx, pt::lbvh_emit_device((const float4*)ctx->d_spheres.p, n, tree, (float4*)ctx->d_bvh_nodes.p, (int2*)ctx->d_bvh_start.p, ctx->stream));
     uint32_t info[pt::kLbvhInfoWords];
     IR_HIP(ctx, hipMemcpyAsync(info, tree.info, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -260,6 +266,8 @@ void fill_bvh(const ir_context* ctx, pt::LbvhView& v) {
     v.wide = (const float4*)ctx->d_bvh_nodes.p;
     v.leaf_spheres = (const float4*)ctx->d_bvh_spheres.p;
     v.leaf_index = (const int*)ctx->d_bvh_index.p;
+    v.sphere_start = (const int2*)ctx->d_bvh_start.p;
+    v.n_inner = ctx->bvh_nodes;
     v.stack_depth = ctx->bvh_stack;
 }
 
@@ -357,7 +365,7 @@ void ir_destroy(ir_context* ctx) {
     release(ctx->d_prim); release(ctx->d_task_pixels); release(ctx->d_task_counters);
     release(ctx->d_wf_queue[0]); release(ctx->d_wf_queue[1]); release(ctx->d_wf_counts); release(ctx->d_wf_values);
     release(ctx->d_wf_prim); release(ctx->d_wf_tileacc);
-    release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index); release(ctx->d_bvh_scratch);
+    release(ctx->d_bvh_nodes); release(ctx->d_bvh_spheres); release(ctx->d_bvh_index); release(ctx->d_bvh_start); release(ctx->d_bvh_scratch);
     release(ctx->d_sky_marginal); release(ctx->d_sky_cond); release(ctx->d_sky_pdf);
     release(ctx->d_sky_marginal_guide); release(ctx->d_sky_cond_guide);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -625,16 +633,25 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     const bool wavefront = ctx->schedule == IR_SCHEDULE_WAVEFRONT && !ctx->stats_enabled;
     const bool owns_all = !(ctx->part_mode == IR_PARTITION_TILES && ctx->world > 1);
     const bool fresh_in_kernel = !accumulate && spp != 0 && n != 0 && !wavefront && owns_all;
+    // Everything that can still refuse the call is checked BEFORE the fills are skipped: an error return must leave a
+    // zeroed film behind a non-accumulating call (as the fills always did), never old sums under samples_done == 0.
+    const float* rays = nullptr;
+    uint64_t base = accumulate ? ctx->samples_done : 0;
+    if (ctx->part_mode == IR_PARTITION_SAMPLES) base = base * ctx->world + (uint64_t)ctx->rank * spp;
+    int refused = IR_OK;
+    if (spp != 0) {
+        refused = check_camera(ctx, width, height, &rays);
+        if (refused == IR_OK && base + spp > 0xffffffffull) refused = fail(ctx, IR_ELIMIT, "%s: sample index overflow", who);
+    }
     if (!accumulate) {
-        if (!fresh_in_kernel) {
+        if (!fresh_in_kernel || refused != IR_OK) {
             IR_HIP(ctx, hipMemsetAsync(sum, 0, n * sizeof(float4), ctx->stream));
             IR_HIP(ctx, hipMemsetAsync(counts, 0, n * sizeof(uint32_t), ctx->stream));
         }
         ctx->samples_done = 0;
     }
+    if (refused != IR_OK) return refused;
     if (spp == 0) return IR_OK;
-    const float* rays = nullptr;
-    IR_TRY(check_camera(ctx, width, height, &rays));
     const int accel = selected_accel(ctx);
     // sky importance sampling needs a sky image; with a constant sky colour there is nothing to importance-sample
     const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
@@ -679,10 +696,11 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         a.stats = (unsigned long long*)ctx->d_stats.p;
     }
 
-    // sample indices of this call
-    uint64_t base = ctx->samples_done;
-    if (ctx->part_mode == IR_PARTITION_SAMPLES) base = (uint64_t)ctx->samples_done * ctx->world + (uint64_t)ctx->rank * spp;
-    if (base + spp > 0xffffffffull) return fail(ctx, IR_ELIMIT, "ir_render: sample index overflow");
+    // sample indices of this call: [base, base + spp), checked above.  The sample block is resolved once, for both
+    // schedules (IR_SAMPLE_BLOCK_AUTO is 0: the wavefront branch must never see it raw).
+    const uint32_t owned_wgs = pt::owned_tiles(a.n_tiles, a.tile_rank, a.tile_world) * pt::kBlocksPerTile;
+    const uint32_t sb = ctx->sample_block ? ctx->sample_block : auto_sample_block(owned_wgs, spp);
+    ctx->last_sample_block = sb;
 
     if (ctx->schedule == IR_SCHEDULE_WAVEFRONT && !ctx->stats_enabled) {
         // queues sized for at least one sample of every owned pixel (rounded to whole 64x64 tiles)
@@ -691,7 +709,7 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         size_t cap = ctx->wf_max_paths;
         if (cap < owned_pixels) cap = owned_pixels;
         size_t per_batch = owned_pixels ? cap / owned_pixels : 1;
-        if (per_batch > ctx->sample_block) per_batch = ctx->sample_block;
+        if (per_batch > sb) per_batch = sb;
         if (per_batch > spp) per_batch = spp;
         pt::WfArgs wa;
         memset(&wa, 0, sizeof(wa));
@@ -717,7 +735,7 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
         wa.r = a;
         wa.r.spp = spp;
         wa.r.sample_base = (uint32_t)base;
-        wa.r.sample_block = ctx->sample_block;
+        wa.r.sample_block = sb;
         wa.prim_pos = (float4*)ctx->d_wf_prim.p;
         wa.prim_nrm = (float4*)ctx->d_wf_prim.p + n;
         wa.values = (float4*)ctx->d_wf_values.p;
@@ -741,9 +759,6 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     const double unit = (double)n * (double)(accel == pt::kAccelLbvh ? 64 : (ctx->n_spheres < 8 ? 8 : ctx->n_spheres));
     uint32_t chunk = (uint32_t)std::fmin(4096.0, std::fmax(1.0, 4.0e12 / unit));
     // whole sample blocks per launch, so that the block structure does not depend on the chunking
-    const uint32_t owned_wgs = pt::owned_tiles(a.n_tiles, a.tile_rank, a.tile_world) * pt::kBlocksPerTile;
-    const uint32_t sb = ctx->sample_block ? ctx->sample_block : auto_sample_block(owned_wgs, spp);
-    ctx->last_sample_block = sb;
     chunk = chunk < sb ? sb : chunk / sb * sb;
     // ... and bound the block sums of one launch (16 B per pixel and block): more launches rather than more memory.  A
     // small sample_block is what a caller sets to get the reference's per-sample sum order; it must not cost 100 GB.
@@ -1113,6 +1128,24 @@ int ir_get_accel_build_info(ir_context* ctx, int* out_builder, double* out_secon
     const bool lbvh = selected_accel(ctx) == pt::kAccelLbvh;
     if (out_builder) *out_builder = lbvh ? ctx->bvh_built_by : IR_BUILD_HOST;
     if (out_seconds) *out_seconds = lbvh ? ctx->bvh_build_seconds : 0.0;
+    return IR_OK;
+}
+
+int ir_download_accel_climb(ir_context* ctx, void* climb_records, uint32_t n_records, int32_t* sphere_start, uint32_t n_spheres) {
+    if (!ctx) return IR_EINVAL;
+    IR_TRY(use_device(ctx));
+    IR_TRY(ensure_bvh(ctx));
+    if (selected_accel(ctx) != pt::kAccelLbvh) return fail(ctx, IR_ESTATE, "ir_download_accel_climb: the scene is rendered with the linear scan");
+    const uint32_t have = ctx->bvh_nodes + ctx->n_spheres;  // records of inner nodes (the root's slot unused) and of leaves, by first position
+    if (n_records != have || n_spheres != ctx->n_spheres)
+        return fail(ctx, IR_EINVAL, "ir_download_accel_climb: the LBVH has %u climb records over %u spheres, buffers are for %u / %u", have,
+                    ctx->n_spheres, n_records, n_spheres);
+    if (climb_records)
+        IR_HIP(ctx, hipMemcpyAsync(climb_records, (const char*)ctx->d_bvh_nodes.p + (size_t)ctx->bvh_nodes * sizeof(pt::WideNode),
+                                   (size_t)n_records * sizeof(pt::WideNode), hipMemcpyDeviceToHost, ctx->stream));
+    if (sphere_start)
+        IR_HIP(ctx, hipMemcpyAsync(sphere_start, ctx->d_bvh_start.p, (size_t)n_spheres * 8, hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IR_OK;
 }
 

@@ -44,7 +44,7 @@ struct ir_context {
     uint32_t n_spheres = 0;
     irx::DeviceBuf d_spheres, d_shade;
     // LBVH (built before the first launch that needs it, on the host or on the device: ir_set_accel_build)
-    irx::DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index, d_bvh_scratch;
+    irx::DeviceBuf d_bvh_nodes, d_bvh_spheres, d_bvh_index, d_bvh_start, d_bvh_scratch;  // d_bvh_nodes: wide nodes + climb records (lbvh.h)
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_stack = 0;
     bool bvh_valid = false;
     int bvh_build = IR_BUILD_AUTO;

@@ -147,6 +147,8 @@ static void build_preorder(const float* spheres_xyzr, uint32_t n, Lbvh& out, boo
 
 void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
     out.wide.clear();
+    out.n_inner = 0;
+    out.sphere_start.clear();
     out.stack_depth = 0;
     out.nodes.clear();
     out.leaf_spheres.clear();
@@ -187,6 +189,61 @@ void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
         }
     }
     out.stack_depth = out.max_depth + 1;
+
+    // climb records (lbvh.h) behind the wide nodes
+    out.n_inner = (uint32_t)out.wide.size();
+    const size_t ni = out.n_inner;
+    WideNode zero;
+    memset(&zero, 0, sizeof(zero));
+    out.wide.resize(2 * ni + n, zero);
+    out.sphere_start.assign(2 * (size_t)n, 0);
+    if (out.nodes[0].leaf >= 0) {  // a single leaf: nothing to climb to
+        for (uint32_t i = 0; i < n; ++i) {
+            out.sphere_start[2 * (size_t)out.leaf_index[i]] = ref[0];
+            out.sphere_start[2 * (size_t)out.leaf_index[i] + 1] = kClimbDone;
+        }
+        return;
+    }
+    std::vector<int32_t> parent(m, -1);
+    for (size_t i = 0; i < m; ++i)
+        if (out.nodes[i].leaf < 0) {
+            parent[i + 1] = (int32_t)i;
+            parent[(size_t)out.nodes[i + 1].skip] = (int32_t)i;
+        }
+    auto sibling = [&](size_t x) {
+        const size_t p = (size_t)parent[x], l = p + 1;
+        return x == l ? (size_t)out.nodes[l].skip : l;
+    };
+    auto record_of = [&](size_t x) -> int32_t {
+        return out.nodes[x].leaf < 0 ? (int32_t)(ni + (size_t)ref[x]) : (int32_t)(2 * ni + (size_t)(out.nodes[x].leaf >> 3));
+    };
+    const uint32_t qnan_bits = 0x7fc00000u;  // the same quiet NaN the device builder writes
+    float nan;
+    memcpy(&nan, &qnan_bits, 4);
+    const float nan3[3] = {nan, nan, nan};
+    for (size_t x = 1; x < m; ++x) {
+        const size_t p = (size_t)parent[x], s = sibling(x);
+        const int32_t g = parent[p];
+        WideNode& w = out.wide[(size_t)record_of(x)];
+        put(w, 0, out.nodes[s].lo, ref[s]);
+        if (g >= 0) {
+            const size_t u = sibling(p);
+            put(w, 1, out.nodes[s].hi, ref[u]);
+            put(w, 2, out.nodes[u].lo, parent[(size_t)g] >= 0 ? record_of((size_t)g) : kClimbDone);
+            put(w, 3, out.nodes[u].hi, 0);
+        } else {
+            put(w, 1, out.nodes[s].hi, -1);
+            put(w, 2, nan3, kClimbDone);
+            put(w, 3, nan3, 0);
+        }
+        if (out.nodes[x].leaf >= 0) {
+            const uint32_t first = (uint32_t)out.nodes[x].leaf >> 3, count = (uint32_t)out.nodes[x].leaf & 7u;
+            for (uint32_t k = 0; k < count; ++k) {
+                out.sphere_start[2 * (size_t)out.leaf_index[first + k]] = ref[x];
+                out.sphere_start[2 * (size_t)out.leaf_index[first + k] + 1] = record_of(x);
+            }
+        }
+    }
 }
 
 }  // namespace pt

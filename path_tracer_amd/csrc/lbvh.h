@@ -35,8 +35,26 @@ struct WideNode {
 };
 constexpr uint32_t kMaxStack = 32;
 
+// Climb records ("start at the leaf the ray stands on"): a bounce ray leaves a sphere whose leaf is known, and every
+// node on the way from the root to that leaf contains the origin, so a top-down traversal spends most of its steps
+// walking down that path (two box tests per level, one of them a foregone conclusion).  A climb starts at the leaf and
+// walks UP instead: at each ancestor only the sibling subtree is left to look at, and one record holds TWO levels of
+// siblings, so the walk covers two levels per step with the same two box tests an inner node takes.  Records have the
+// wide-node layout and live in the same array (`wide`), after the n_inner wide nodes:
+//   record of inner node i (i >= 1)        at n_inner + i           (slot n_inner + 0, the root's, is unused: zeros)
+//   record of the leaf starting at first   at 2 * n_inner + first   (positions that start no leaf: zeros)
+//   [0] = (sibling.lo, sibling ref)  [1] = (sibling.hi, uncle ref)  [2] = (uncle.lo, next record)  [3] = (uncle.hi, 0)
+// sibling = the other child of the node's parent, uncle = the other child of its grandparent (a NaN box that no ray
+// hits, ref -1, when the parent is the root), next = record of the grandparent, or kClimbDone when the grandparent is
+// the root or missing.  Visiting order never enters the result (lbvh.h top), and every leaf is either the start leaf
+// or inside exactly one sibling subtree of the start leaf's ancestors, so a climb tests what a top-down traversal tests.
+// sphere_start[original index] = (leaf ref, record of that leaf or kClimbDone).
+constexpr int32_t kClimbDone = 0x7fffffff;  // == pt::kCursorDone (pt_device.h)
+
 struct Lbvh {
-    std::vector<WideNode> wide;
+    std::vector<WideNode> wide;       // n_inner wide nodes, then the climb records (2 * n_inner + n entries in all)
+    uint32_t n_inner = 0;
+    std::vector<int32_t> sphere_start;  // 2 per sphere, by original index
     uint32_t stack_depth = 0;
     std::vector<BvhNode> nodes;
     std::vector<float> leaf_spheres;   // 4 floats per sphere in leaf order: cx, cy, cz, r*r

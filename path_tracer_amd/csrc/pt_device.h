@@ -361,9 +361,11 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
 // (Until round 2 the pad was 2^-7 of the L1 distance: 10 % more node visits and 17 % more leaf tests on the 10k scene.)
 // ----------------------------------------------------------------------------------------------------
 struct LbvhView {
-    const float4* __restrict__ wide;          // 4 x float4 per inner node (lbvh.h WideNode)
+    const float4* __restrict__ wide;          // 4 x float4 per record (lbvh.h WideNode): n_inner wide nodes, then climb records
     const float4* __restrict__ leaf_spheres;  // leaf order: (cx, cy, cz, r*r)
     const int* __restrict__ leaf_index;       // leaf order -> original sphere index
+    const int2* __restrict__ sphere_start;    // original sphere index -> (leaf ref, climb record or kCursorDone), lbvh.h
+    uint32_t n_inner;                         // records below it are wide nodes, records from it on are climb records
     uint32_t stack_depth;                     // entries a traversal may need (<= kMaxStack)
 };
 
@@ -383,7 +385,9 @@ struct LbvhCursor {
     float a4, a2, ix, iy, iz;
     float best;
     int idx;       // winner so far as a LEAF-ORDER position (-1: none); cursor_hit_index() translates it at the end
-    int cur;       // >= 0: inner node, < 0: leaf -(first * 8 + count) - 1, kCursorDone: finished
+    int cur;       // >= 0: record (inner node below n_inner, climb record from n_inner on), < 0: leaf -(first * 8 + count) - 1,
+                   // kCursorDone: finished
+    int up;        // where the traversal goes on when the stack runs empty: the next climb record, or kCursorDone
     uint32_t sp;   // stack entries in use
 };
 PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
@@ -400,7 +404,18 @@ PT_DEV void cursor_begin(LbvhCursor& c, f3 o, f3 d) {
     c.best = kF32Max;
     c.idx = -1;
     c.cur = 0;
+    c.up = kCursorDone;
     c.sp = 0;
+}
+// A ray that leaves a sphere starts at that sphere's leaf and climbs (lbvh.h "Climb records"): the leaf first, then the
+// sibling subtrees of its ancestors, two levels per record.  start = LbvhView::sphere_start[sphere].  Same (t, index) as
+// a traversal from the root, whatever `start` is: it only decides the visiting order.
+PT_DEV void cursor_begin_at(LbvhCursor& c, f3 o, f3 d, int2 start) {
+    cursor_begin(c, o, d);
+#ifndef IR_NO_CLIMB  // (tools/ A/B builds: every traversal from the root)
+    c.cur = start.x;
+    c.up = start.y;
+#endif
 }
 #ifndef IR_BOX_PAD
 #define IR_BOX_PAD 0.003f  // other values only in tools/ experiments (they void the parity guarantee)
@@ -419,13 +434,15 @@ PT_DEV bool padded_box_hit(const LbvhCursor& c, float4 lo, float4 hi, float& tmi
     const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
     return (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= c.best);
 }
+// An empty stack hands the traversal to the next climb record (kCursorDone when there is none: a traversal from the root,
+// or a climb that has reached it).  c.up is not cleared here: the record it names overwrites it when it is stepped.
 PT_DEV int cursor_pop(LbvhCursor& c, const int* stack, uint32_t stride) {
-    if (c.sp == 0) return kCursorDone;
+    if (c.sp == 0) return c.up;
     c.sp--;
     return stack[c.sp * stride];
 }
-// Precondition: c.cur >= 0 (inner node).  Tests both children, enters the nearer hit child and pushes the farther;
-// with no child hit, pops.  Afterwards c.cur is an inner node, a leaf (< 0) or kCursorDone.
+// Precondition: c.cur >= 0 and != kCursorDone (a record).  Tests both boxes, enters the nearer hit one and pushes the
+// farther; with none hit, pops.  Afterwards c.cur is a record, a leaf (< 0) or kCursorDone.
 template <bool STATS>
 PT_DEV void cursor_inner_step(const LbvhView& v, LbvhCursor& c, int* stack, uint32_t stride, uint32_t& node_visits) {
     const size_t at = 4 * (size_t)c.cur;
@@ -434,6 +451,12 @@ PT_DEV void cursor_inner_step(const LbvhView& v, LbvhCursor& c, int* stack, uint
     float tl, tr;
     const bool hl = padded_box_hit(c, n0, n1, tl), hr = padded_box_hit(c, n2, n3, tr);
     const int rl = __builtin_bit_cast(int, n0.w), rr = __builtin_bit_cast(int, n1.w);
+    // a climb record: the same two box tests (sibling and uncle subtrees), and it names the record two levels up in the
+    // word a wide node leaves zero (no record has index 0).  Deciding on the loaded word keeps this ONE 16-byte load: a
+    // test of c.cur against n_inner made the compiler fetch the word with a fifth, conditional load, and the kernel is
+    // bound by the L1 data path.
+    const int next_up = __builtin_bit_cast(int, n2.w);
+    if (next_up != 0) c.up = next_up;
     // Written with selects around ONE push and ONE pop: the four-way if/else cascade cost the divergent wave four nested
     // exec-mask regions (35 scalar instructions per step, a fifth of the step).
     const bool both = hl && hr, any = hl || hr;

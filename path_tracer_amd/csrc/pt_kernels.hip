@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                     if (SKYMIS && shadow) {
                         if (cur.idx < 0) light = light + sky_term;
                         shadow = false;
-                        cursor_begin(cur, cur.o, wi_next);  // the bounce ray leaves the same point as the shadow ray
+                        cursor_begin_at(cur, cur.o, wi_next, a.bvh.sphere_start[idx]);  // the bounce ray leaves the same point as the shadow ray
                         traversing = true;
                     } else if (cur.idx >= 0) {
                         if (STATS) n_hits++;
@@ -682,6 +682,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                     // shade the hit of bounce b (integrator.rs:50-81)
                     const float4 m_brdf = a.shade[2 * idx];
                     const float4 m_emit = a.shade[2 * idx + 1];
+                    // the next ray leaves sphere idx: its traversal starts at that sphere's leaf and climbs (lbvh.h)
+                    const int2 start = a.bvh.sphere_start[idx];
                     light = light + mk3(m_emit.x, m_emit.y, m_emit.z) * contrib;
                     const float r1 = draw(skey, 3 * b);
                     const float r2 = draw(skey, 3 * b + 1);
@@ -722,13 +724,17 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                                     sky_term = (sk * contrib) * (pa / (pe + pa));
                                     wi_next = wi;
                                     shadow = true;
-                                    cursor_begin(cur, cur.o, ws);
+                                    cursor_begin_at(cur, cur.o, ws, start);
                                     traversing = true;
                                     break;
                                 }
                             }
-                            cursor_begin(cur, cur.o, wi);
-                            traversing = true;
+                            cursor_begin_at(cur, cur.o, wi, start);
+                            // the start leaf right here, with every lane of the shading block, instead of as the first of
+                            // the wave's thinly populated leaf steps (C3 +1.8 %, profiles/r3_same_box_ab.txt)
+                            if (cur.cur < 0) cursor_leaf_step<STATS>(a.bvh, cur, stack, 256u, wc.disc, wc.leaves);
+                            traversing = cur.cur != kCursorDone;
+                            landed = !traversing;
                             break;
                         }
                     }

@@ -14,7 +14,9 @@
 //                                order, so the zero signs match the host's too) and counts the node's inner nodes;
 //                                nodes inside one workgroup's positions first, the straddling ones in one workgroup
 //   lb_emit                      nodes of >= 3 spheres become 64-byte wide nodes, numbered in pre-order: a node's
-//                                rank is the sum over its ancestors of 1 + (inner nodes of the left sibling subtree)
+//                                rank is the sum over its ancestors of 1 + (inner nodes of the left sibling subtree);
+//                                the same thread writes the climb records of the node's two children (lbvh.h) and the
+//                                traversal start of the spheres in its leaf children
 //   lb_leaves                    leaf-ordered sphere and index arrays
 // Ranges of <= kLeafMax spheres are leaves, exactly as in the host build, so the two builders give byte-identical
 // arrays (tests/test_gpu_lbvh_build.py).
@@ -291,9 +293,20 @@ __device__ __forceinline__ void child_entry(const float4* __restrict__ spheres, 
     *ref = count <= (int)kLeafMax ? -(lo * 8 + count) - 1 : rank;
 }
 
+// One climb record (lbvh.h "Climb records"): `sib` = the other child of the node's parent, `unc` = the other child of its
+// grandparent (has_uncle == false: the parent is the root).
+__device__ __forceinline__ void put_climb(float4* __restrict__ rec, const Box& sib, int sib_ref, bool has_uncle, const Box& unc, int unc_ref,
+                                          int next) {
+    const float nan = __uint_as_float(0x7fc00000u);  // the host build's quiet NaN: a box no ray hits
+    rec[0] = make_float4(sib.lo[0], sib.lo[1], sib.lo[2], __int_as_float(sib_ref));
+    rec[1] = make_float4(sib.hi[0], sib.hi[1], sib.hi[2], __int_as_float(has_uncle ? unc_ref : -1));
+    rec[2] = has_uncle ? make_float4(unc.lo[0], unc.lo[1], unc.lo[2], __int_as_float(next)) : make_float4(nan, nan, nan, __int_as_float(next));
+    rec[3] = has_uncle ? make_float4(unc.hi[0], unc.hi[1], unc.hi[2], 0.0f) : make_float4(nan, nan, nan, 0.0f);
+}
+
 __global__ void __launch_bounds__(kBlock) lb_emit(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, int n,
                                                   const int4* __restrict__ nodes, const float4* __restrict__ boxes,
-                                                  float4* __restrict__ wide, uint32_t* info) {
+                                                  float4* __restrict__ wide, int2* __restrict__ sphere_start, uint32_t* info) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n - 1) return;
     const int4 nd = nodes[i];
@@ -318,7 +331,31 @@ __global__ void __launch_bounds__(kBlock) lb_emit(const float4* __restrict__ sph
     w[2] = make_float4(br.lo[0], br.lo[1], br.lo[2], 0.0f);
     w[3] = make_float4(br.hi[0], br.hi[1], br.hi[2], 0.0f);
     atomicMax(&info[6], (uint32_t)depth + 1u);  // the children are one level below
-    if (i == 0) info[7] = (uint32_t)__float_as_int(boxes[0].w);
+    const int n_inner = __float_as_int(boxes[0].w);
+    if (i == 0) info[7] = (uint32_t)n_inner;
+
+    // Climb records of this node's two children: their sibling is the other child, their uncle is this node's sibling,
+    // their grandparent this node's parent.
+    Box bu = bl;
+    int ru = -1, next = kClimbDone;
+    const bool has_uncle = nd.w >= 0;
+    if (has_uncle) {
+        const int4 a = nodes[nd.w];
+        const bool i_is_left = nd.x == a.x;
+        const int a_left_inner = (a.z - a.x + 1 > (int)kLeafMax) ? __float_as_int(boxes[2 * a.z].w) : 0;
+        const int parent_rank = i_is_left ? rank - 1 : rank - 1 - a_left_inner;
+        if (i_is_left) child_entry(spheres, order, boxes, a.z + 1, a.y, a.z + 1, parent_rank + 1 + a_left_inner, &bu, &ru);
+        else child_entry(spheres, order, boxes, a.x, a.z, a.z, parent_rank + 1, &bu, &ru);
+        if (a.w >= 0) next = n_inner + parent_rank;
+    }
+    const int rec_l = rl >= 0 ? n_inner + rl : 2 * n_inner + nd.x;
+    const int rec_r = rr >= 0 ? n_inner + rr : 2 * n_inner + nd.z + 1;
+    put_climb(wide + 4 * (size_t)rec_l, br, rr, has_uncle, bu, ru, next);
+    put_climb(wide + 4 * (size_t)rec_r, bl, rl, has_uncle, bu, ru, next);
+    if (rl < 0)
+        for (int j = nd.x; j <= nd.z; ++j) sphere_start[order[j]] = make_int2(rl, rec_l);
+    if (rr < 0)
+        for (int j = nd.z + 1; j <= nd.y; ++j) sphere_start[order[j]] = make_int2(rr, rec_r);
 }
 
 __global__ void __launch_bounds__(kBlock) lb_leaves(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, uint32_t n,
@@ -421,10 +458,11 @@ hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch,
     return hipSuccess;
 }
 
-hipError_t lbvh_emit_device(const float4* d_spheres, uint32_t n, const LbvhDeviceTree& tree, float4* d_wide, hipStream_t stream) {
+hipError_t lbvh_emit_device(const float4* d_spheres, uint32_t n, const LbvhDeviceTree& tree, float4* d_wide, int2* d_sphere_start,
+                            hipStream_t stream) {
     const uint32_t blocks = (n + kBlock - 1) / kBlock;
     lb_emit<<<blocks, kBlock, 0, stream>>>(d_spheres, (const uint32_t*)tree.order, (int)n, (const int4*)tree.nodes,
-                                           (const float4*)tree.boxes, d_wide, (uint32_t*)tree.info);
+                                           (const float4*)tree.boxes, d_wide, d_sphere_start, (uint32_t*)tree.info);
     return hipGetLastError();
 }
 

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void wf_bounce_tree(const WfAr
                     if (SKYMIS && shadow) {
                         if (cur.idx < 0) p.light = p.light + sky_term;
                         shadow = false;
-                        cursor_begin(cur, cur.o, wi_next);  // the bounce ray leaves the same point as the shadow ray
+                        cursor_begin_at(cur, cur.o, wi_next, a.r.bvh.sphere_start[p.idx]);  // the bounce ray leaves the same point as the shadow ray
                         traversing = true;
                     } else {
                         if (cur.idx >= 0) {
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void wf_bounce_tree(const WfAr
                     const uint32_t skey = sample_key(a.r.seed_hi, pixel_key(a.r.seed_lo, p.pix), a.r.sample_base + a.batch_first + p.smp);
                     const float4 m_brdf = a.r.shade[2 * p.idx];
                     const float4 m_emit = a.r.shade[2 * p.idx + 1];
+                    const int2 start = a.r.bvh.sphere_start[p.idx];  // the next ray starts at this sphere's leaf and climbs (lbvh.h)
                     p.light = p.light + mk3(m_emit.x, m_emit.y, m_emit.z) * p.contrib;
                     const float r1 = draw(skey, 3 * b);
                     const float r2 = draw(skey, 3 * b + 1);
@@ -434,10 +435,10 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void wf_bounce_tree(const WfAr
                                 wi_next = wi;
                                 shadow = true;
                                 shadow_first = true;
-                                cursor_begin(cur, o, ws);
+                                cursor_begin_at(cur, o, ws, start);
                             }
                         }
-                        if (!shadow_first) cursor_begin(cur, o, wi);
+                        if (!shadow_first) cursor_begin_at(cur, o, wi, start);
                         traversing = true;
                     } else {  // roulette / bounce budget: no sky term (integrator.rs:47,74,92)
                         a.values[(size_t)p.smp * npix + p.pix] = make_float4(p.light.x, p.light.y, p.light.z, 0.0f);

@@ -152,6 +152,17 @@ class RayTracer:
                                                            index.ctypes.data_as(_capi.c_i32_p), n))
         return wide, leaf, index
 
+    def download_accel_climb(self):
+        """The LBVH's climb records ((nodes + n, 16) f32, refs are int32 bit patterns) and the per-sphere traversal start
+        ((n, 2) int32: leaf ref, record), lbvh.h "Climb records"."""
+        info = self.get_accel_info()
+        n = getattr(self, "_n_spheres", 0)
+        rec = np.zeros((info["nodes"] + n, 16), dtype=np.float32)
+        start = np.zeros((n, 2), dtype=np.int32)
+        _capi.check(self._ctx, _capi.lib.ir_download_accel_climb(self._ctx, rec.ctypes.data_as(C.c_void_p), info["nodes"] + n,
+                                                                 start.ctypes.data_as(_capi.c_i32_p), n))
+        return rec, start
+
     def get_radiance(self):
         """Accumulator.framebuffer / sample_counts (full_buffer.rs:7-12): (h, w, 4) f32 sums and (h, w) u32."""
         w, h = self.get_current_size()

@@ -33,6 +33,7 @@ extern "C" {
     pub fn ir_set_accel_build(ctx: *mut ir_context, build: c_int) -> c_int;
     pub fn ir_get_accel_build_info(ctx: *mut ir_context, out_builder: *mut c_int, out_seconds: *mut f64) -> c_int;
     pub fn ir_download_accel(ctx: *mut ir_context, wide_nodes: *mut c_void, n_nodes: u32, leaf_spheres: *mut f32, leaf_index: *mut i32, n_spheres: u32) -> c_int;
+    pub fn ir_download_accel_climb(ctx: *mut ir_context, climb_records: *mut c_void, n_records: u32, sphere_start: *mut i32, n_spheres: u32) -> c_int;
     pub fn ir_set_pinhole(ctx: *mut ir_context, local_to_world: *const c_float, position: *const c_float, fov: c_float, aspect_ratio: c_float) -> c_int;
     pub fn ir_set_primary_rays(ctx: *mut ir_context, rays: *const c_float, w: u32, h: u32) -> c_int;
     pub fn ir_pinhole_compute(position: *const c_float, rotation_xyz: *const c_float, focal_length: c_float, sensor_size: c_float,

@@ -147,6 +147,35 @@ def test_limits_are_errors_not_crashes(pta, tracer):
     assert (tracer.get_radiance()[1] == 2).all()
 
 
+def test_refused_non_accumulating_render_leaves_a_zeroed_film(pta):
+    """A non-accumulating render that is refused after the reset (no camera set) must not leave old sums under
+    samples_done == 0: the fills that the task schedule normally folds into its primary pass are issued on the error path."""
+    import ctypes as C
+    from path_tracer_amd import _capi, workloads as W
+    w, h = 64, 40
+    rt = pta.RayTracer(0, 0, device=0)
+    try:
+        ctx = rt._ctx
+        # scene through the mirror, no camera at all: a frame is sized and rendered by hand through the C ABI
+        rt._upload_scene(W.scene_s1(skybox=None))
+        assert _capi.lib.ir_render(ctx, w, h, 0, 0) == _capi.IR_OK          # sizes the film
+        ones = np.ones((h, w, 4), dtype=np.float32)
+        rt.set_radiance(ones, np.full((h, w), 3, dtype=np.uint32))
+        rt.set_samples_accumulated(3)
+        rc = _capi.lib.ir_render(ctx, w, h, 4, 0)
+        assert rc == _capi.IR_ESTATE, _capi.lib.ir_last_error(ctx)
+        s, c = rt.get_radiance()
+        assert rt.samples_accumulated() == 0 and not s.any() and not c.any()
+        # an accumulating render that is refused changes nothing
+        rt.set_radiance(ones, np.full((h, w), 3, dtype=np.uint32))
+        rt.set_samples_accumulated(3)
+        assert _capi.lib.ir_render(ctx, w, h, 4, 1) == _capi.IR_ESTATE
+        s, c = rt.get_radiance()
+        assert rt.samples_accumulated() == 3 and (s == 1.0).all() and (c == 3).all()
+    finally:
+        rt.close()
+
+
 def test_mapped_output_equals_copied_output(pta, tracer):
     """ir_map_output_argb (the reference's borrowed `&[u32]`, renderer.rs:164-169) against ir_get_output_argb's copy."""
     import ctypes as C

@@ -1,5 +1,5 @@
 """Device LBVH build (pt_lbvh_build.hip) against the host build (lbvh.cpp): the two builders must give byte-identical
-wide nodes, leaf spheres and leaf indices, and therefore the same hits; both equal the reference's linear scan
+wide nodes, leaf spheres, leaf indices, climb records and traversal starts, and therefore the same hits; both equal the reference's linear scan
 (integrator.rs:106-127), checked through the oracle where the scan is affordable.
 
 Scenes cover what the radix tree has to get right: distinct codes, long runs of equal Morton codes (which continue on
@@ -98,7 +98,7 @@ def _build(tracer, scene, cam, w, h, build):
         idx, t = tracer.get_primary_hits(scene, w, h, with_t=True)
         info = tracer.get_accel_info()
         binfo = tracer.get_accel_build_info()
-        arrays = tracer.download_accel()
+        arrays = tracer.download_accel() + tracer.download_accel_climb()
     finally:
         tracer.set_accel_build(_capi.IR_BUILD_AUTO)
         tracer.set_accel(_capi.IR_ACCEL_AUTO)
@@ -121,10 +121,19 @@ def test_device_build_equals_host_build(pta, tracer, oracle, kind, n):
     assert hb["builder"] == _capi.IR_BUILD_HOST and db["builder"] == _capi.IR_BUILD_DEVICE
     assert hinfo == dinfo, (hinfo, dinfo)
     assert hinfo["nodes"] >= 1 and hinfo["depth"] >= 1
-    for name, a, b in zip(("wide", "leaf_spheres", "leaf_index"), harr, darr):
+    for name, a, b in zip(("wide", "leaf_spheres", "leaf_index", "climb_records", "sphere_start"), harr, darr):
         assert a.shape == b.shape, name
         assert a.tobytes() == b.tobytes(), f"{name}: {np.count_nonzero(a.view(np.uint32) != b.view(np.uint32))} words differ"
     assert np.array_equal(np.sort(harr[2]), np.arange(n, dtype=np.int32))
+    # every sphere starts at a leaf that holds it, and its climb record (if the tree has more than the one leaf) exists
+    start = harr[4]
+    leaf = -(start[:, 0] + 1)
+    first, count = leaf >> 3, leaf & 7
+    pos = np.empty(n, dtype=np.int64)
+    pos[harr[2]] = np.arange(n)
+    assert ((pos >= first) & (pos < first + count)).all()
+    has_record = start[:, 1] != 0x7fffffff
+    assert (start[has_record, 1] == 2 * hinfo["nodes"] + first[has_record]).all()
     assert hidx.tobytes() == didx.tobytes() and ht.tobytes() == dt.tobytes()
     if n <= 10000:
         oidx, ot = oracle.primary_hits(oracle.camera_from(cam, w, h), scene)

@@ -96,3 +96,35 @@ def test_wavefront_tile_partition(pta, tracer):
         tracer.set_partition(_capi.IR_PARTITION_NONE, 0, 1)
         tracer.set_schedule(_capi.IR_SCHEDULE_AUTO)
     assert np.array_equal(acc.view(np.uint32), whole.view(np.uint32)) and np.array_equal(cnt, wc)
+
+
+@pytest.mark.parametrize("scene_kind", ["s1", "s2"])
+def test_wavefront_with_auto_sample_block(pta, tracer, oracle, scene_kind):
+    """IR_SAMPLE_BLOCK_AUTO (0) must be resolved before the wavefront branch uses it (it once reached the queues raw: a
+    zero-sample batch and IR_EDEVICE).  Same bits as regeneration and the oracle, with the block ir_get_sample_block names."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h, spp = (160, 90, 40) if scene_kind == "s1" else (128, 72, 12)
+    scene = W.scene_s1() if scene_kind == "s1" else W.scene_s2(n=500)
+    cam = W.default_camera(w, h) if scene_kind == "s1" else W.camera_s2(w, h)
+    tracer.set_sample_block(_capi.IR_SAMPLE_BLOCK_AUTO)
+    try:
+        sb = tracer.get_sample_block(w, h, spp)
+        assert 0 < sb < spp          # several blocks: the order of the block sums matters
+        s, c = _both(pta, tracer, scene, cam, w, h, spp, 8, 2, accumulate_more=5)
+        oracle.set_sample_block(sb)
+        oc = oracle.camera_from(cam, w, h)
+        os_, ocnt, _, _ = oracle.render(oc, scene, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1)
+    finally:
+        tracer.set_sample_block(128)
+        oracle.set_sample_block(128)
+    assert (c == spp + 5).all()
+    # (the oracle comparison covers the first call: render it again alone)
+    tracer.set_sample_block(_capi.IR_SAMPLE_BLOCK_AUTO)
+    try:
+        tracer.set_schedule(_capi.IR_SCHEDULE_WAVEFRONT)
+        tracer.render(scene, w, h, False, spp=spp)
+        s1, c1 = tracer.get_radiance()
+    finally:
+        tracer.set_schedule(_capi.IR_SCHEDULE_AUTO)
+        tracer.set_sample_block(128)
+    assert np.array_equal(c1, ocnt) and np.array_equal(s1.view(np.uint32), os_.view(np.uint32))
