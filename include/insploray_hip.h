@@ -115,7 +115,7 @@ int ir_set_accel_build(ir_context* ctx, int build);
 /* Builder that produced the current LBVH (IR_BUILD_HOST / IR_BUILD_DEVICE / IR_BUILD_REFIT) and the wall time of that build in
  * seconds, uploads and synchronisation included.  Builds the LBVH if it is selected and stale. */
 int ir_get_accel_build_info(ir_context* ctx, int* out_builder, double* out_seconds);
-/* Copies the LBVH arrays to the host (for inspection and tests): n_nodes x 64-byte wide nodes (layout in
+/* Copies the LBVH arrays to the host (for inspection and tests): n_nodes x 48-byte wide nodes (layout in
  * path_tracer_amd/csrc/lbvh.h), n_spheres x 4 floats (cx, cy, cz, r*r) and n_spheres original indices in leaf
  * order.  n_nodes / n_spheres must equal ir_get_accel_info's node count / the scene's sphere count; any pointer
  * may be NULL.  IR_ESTATE when the scene is rendered with the linear scan. */
@@ -123,7 +123,7 @@ int ir_download_accel(ir_context* ctx, void* wide_nodes, uint32_t n_nodes, float
                       uint32_t n_spheres);
 /* The rest of the LBVH (for inspection and tests): the climb records that let a bounce ray start its traversal at the
  * leaf of the sphere it leaves (layout in path_tracer_amd/csrc/lbvh.h "Climb records": n_records = node count +
- * n_spheres entries of 64 bytes, those of the inner nodes first, then those of the leaves by first leaf position) and,
+ * n_spheres entries of 48 bytes, those of the inner nodes first, then those of the leaves by first leaf position) and,
  * per sphere in original order, two int32: the sphere's leaf reference and that leaf's record (0x7fffffff: none).  The
  * reference has no acceleration structure (integrator.rs:106-127 is the scan these arrays prune).  Either pointer may be
  * NULL.  IR_ESTATE when the scene is rendered with the linear scan. */

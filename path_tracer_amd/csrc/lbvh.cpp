@@ -163,29 +163,21 @@ void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
     std::vector<int32_t> ref(m);
     int32_t n_inner = 0;
     for (size_t i = 0; i < m; ++i) ref[i] = out.nodes[i].leaf < 0 ? n_inner++ : -(out.nodes[i].leaf + 1);
-    auto put = [](WideNode& w, int row, const float* xyz, int32_t word) {
-        w.v[4 * row + 0] = xyz[0];
-        w.v[4 * row + 1] = xyz[1];
-        w.v[4 * row + 2] = xyz[2];
-        memcpy(&w.v[4 * row + 3], &word, 4);
+    auto put = [](WideNode& w, const BvhNode& a, int32_t a_ref, const BvhNode* b, int32_t b_ref, int32_t next_record) {
+        uint32_t words[12];
+        pack_record(a.lo, a.hi, a_ref, b ? b->lo : nullptr, b ? b->hi : nullptr, b_ref, next_record, words);
+        memcpy(w.v, words, sizeof(words));
     };
     if (out.nodes[0].leaf >= 0) {  // the whole tree is one leaf: root with that leaf on the left, an empty leaf on the right
         WideNode w;
-        put(w, 0, out.nodes[0].lo, ref[0]);
-        put(w, 1, out.nodes[0].hi, -1);  // first 0, count 0
-        put(w, 2, out.nodes[0].lo, 0);
-        put(w, 3, out.nodes[0].hi, 0);
+        put(w, out.nodes[0], ref[0], &out.nodes[0], -1 /* first 0, count 0 */, 0);
         out.wide.push_back(w);
     } else {
         out.wide.resize((size_t)n_inner);
         for (size_t i = 0; i < m; ++i) {
             if (out.nodes[i].leaf >= 0) continue;
             const size_t l = i + 1, r = (size_t)out.nodes[l].skip;
-            WideNode& w = out.wide[(size_t)ref[i]];
-            put(w, 0, out.nodes[l].lo, ref[l]);
-            put(w, 1, out.nodes[l].hi, ref[r]);
-            put(w, 2, out.nodes[r].lo, 0);
-            put(w, 3, out.nodes[r].hi, 0);
+            put(out.wide[(size_t)ref[i]], out.nodes[l], ref[l], &out.nodes[r], ref[r], 0);
         }
     }
     out.stack_depth = out.max_depth + 1;
@@ -217,24 +209,15 @@ void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
     auto record_of = [&](size_t x) -> int32_t {
         return out.nodes[x].leaf < 0 ? (int32_t)(ni + (size_t)ref[x]) : (int32_t)(2 * ni + (size_t)(out.nodes[x].leaf >> 3));
     };
-    const uint32_t qnan_bits = 0x7fc00000u;  // the same quiet NaN the device builder writes
-    float nan;
-    memcpy(&nan, &qnan_bits, 4);
-    const float nan3[3] = {nan, nan, nan};
     for (size_t x = 1; x < m; ++x) {
         const size_t p = (size_t)parent[x], s = sibling(x);
         const int32_t g = parent[p];
         WideNode& w = out.wide[(size_t)record_of(x)];
-        put(w, 0, out.nodes[s].lo, ref[s]);
         if (g >= 0) {
             const size_t u = sibling(p);
-            put(w, 1, out.nodes[s].hi, ref[u]);
-            put(w, 2, out.nodes[u].lo, parent[(size_t)g] >= 0 ? record_of((size_t)g) : kClimbDone);
-            put(w, 3, out.nodes[u].hi, 0);
+            put(w, out.nodes[s], ref[s], &out.nodes[u], ref[u], parent[(size_t)g] >= 0 ? record_of((size_t)g) : kClimbDone);
         } else {
-            put(w, 1, out.nodes[s].hi, -1);
-            put(w, 2, nan3, kClimbDone);
-            put(w, 3, nan3, 0);
+            put(w, out.nodes[s], ref[s], nullptr, -1, kClimbDone);
         }
         if (out.nodes[x].leaf >= 0) {
             const uint32_t first = (uint32_t)out.nodes[x].leaf >> 3, count = (uint32_t)out.nodes[x].leaf & 7u;

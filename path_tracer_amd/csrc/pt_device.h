@@ -358,10 +358,14 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
 //     room for the slab test's own roundings (subtraction, hardware reciprocal, product: < 5u = 3e-7 of a slab
 //     distance, against a margin of 1.6e-4 L): P lies inside the padded box, hence tmin <= t <= tmax, tmax > 0, and
 //     tmin <= t <= best whenever the sphere could still win.  No sphere the scan would accept with t <= best is pruned.
+//   * a record stores the box as centre + half extent (f16, rounded up): a box that contains the builder's, so everything
+//     above holds for it; the test takes L = max_k(|centre_k - o_k| + e_k), which is >= that box's far-corner distance,
+//     and evaluates slab k as RN(RN(d_k i_k) -+ RN((e_k + pad) |i_k|)): three roundings and the reciprocal's ulp, < 4u of
+//     (|d_k| + e_k + pad) |i_k| <= 1.003 L |i_k|, i.e. < 2.4e-7 L |i_k| against the margin of 1.6e-4 L |i_k|.
 // (Until round 2 the pad was 2^-7 of the L1 distance: 10 % more node visits and 17 % more leaf tests on the 10k scene.)
 // ----------------------------------------------------------------------------------------------------
 struct LbvhView {
-    const float4* __restrict__ wide;          // 4 x float4 per record (lbvh.h WideNode): n_inner wide nodes, then climb records
+    const float4* __restrict__ wide;          // 3 x float4 per record (lbvh.h WideNode): n_inner wide nodes, then climb records
     const float4* __restrict__ leaf_spheres;  // leaf order: (cx, cy, cz, r*r)
     const int* __restrict__ leaf_index;       // leaf order -> original sphere index
     const int2* __restrict__ sphere_start;    // original sphere index -> (leaf ref, climb record or kCursorDone), lbvh.h
@@ -373,6 +377,16 @@ struct LbvhView {
 // LBVH kernel interleaves steps of different lanes' rays with shading (paths_lbvh_kernel), trace_lbvh runs one to
 // the end.  The stack lives outside (LDS on the device: entry k of this lane at stack[k * stride]).
 constexpr int kCursorDone = 0x7fffffff;
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline float half_bits_to_float(uint32_t h) {  // host builds of the traversal (tests/cpp): f16 -> f32 by hand
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    float v;
+    if (e == 0) v = (float)m * 5.9604644775390625e-08f;  // m * 2^-24
+    else if (e == 31) v = m ? __builtin_nanf("") : __builtin_inff();
+    else v = __builtin_ldexpf((float)(m | 1024u), (int)e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+#endif
 PT_DEV float box_rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rcpf(x);
@@ -421,18 +435,34 @@ PT_DEV void cursor_begin_at(LbvhCursor& c, f3 o, f3 d, int2 start) {
 #define IR_BOX_PAD 0.003f  // other values only in tools/ experiments (they void the parity guarantee)
 #endif
 constexpr float kBoxPad = IR_BOX_PAD;
-PT_DEV bool padded_box_hit(const LbvhCursor& c, float4 lo, float4 hi, float& tmin) {
-    const float lx = lo.x - c.o.x, ly = lo.y - c.o.y, lz = lo.z - c.o.z;
-    const float hx = hi.x - c.o.x, hy = hi.y - c.o.y, hz = hi.z - c.o.z;
-    const float pad = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(lx), __builtin_fabsf(hx)), __builtin_fmaxf(__builtin_fabsf(ly), __builtin_fabsf(hy))),
-                                      __builtin_fmaxf(__builtin_fabsf(lz), __builtin_fabsf(hz))) * kBoxPad;
-    const float t1x = (lx - pad) * c.ix, t2x = (hx + pad) * c.ix;
-    const float t1y = (ly - pad) * c.iy, t2y = (hy + pad) * c.iy;
-    const float t1z = (lz - pad) * c.iz, t2z = (hz + pad) * c.iz;
-    // fmin/fmax return the non-NaN operand: a 0*inf slab (origin on the padded plane, d == 0) is unconstrained
-    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fminf(t1y, t2y)), __builtin_fminf(t1z, t2z));
-    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fmaxf(t1y, t2y)), __builtin_fmaxf(t1z, t2z));
+// Box given as centre and half extent (lbvh.h: a record stores the half extent as f16, rounded up).  d = centre - o,
+// L = max_k(|d_k| + e_k) >= the max-norm distance from the origin to the farthest corner, slab k = d_k i_k -+ (e_k + pad) |i_k|
+// (no min / max per axis: the half width is never negative).  A 0 * inf product (d_k == 0 or e_k + pad == 0 on an axis the ray
+// is parallel to) is NaN and leaves the axis unconstrained (fmin / fmax return the other operand); an axis-parallel ray that
+// passes outside the slab is NOT pruned by this form (inf - inf), which costs such a ray visits, never a hit.  A NaN half
+// extent (the missing uncle of a climb record) makes every comparison false: no hit.
+PT_DEV bool padded_box_hit(const LbvhCursor& c, f3 centre, f3 e, float& tmin) {
+    const float dx = centre.x - c.o.x, dy = centre.y - c.o.y, dz = centre.z - c.o.z;
+    const float pad = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(dx) + e.x, __builtin_fabsf(dy) + e.y), __builtin_fabsf(dz) + e.z) * kBoxPad;
+    const float tcx = dx * c.ix, tcy = dy * c.iy, tcz = dz * c.iz;
+    const float hx = (e.x + pad) * __builtin_fabsf(c.ix), hy = (e.y + pad) * __builtin_fabsf(c.iy), hz = (e.z + pad) * __builtin_fabsf(c.iz);
+    tmin = __builtin_fmaxf(__builtin_fmaxf(tcx - hx, tcy - hy), tcz - hz);
+    const float tmax = __builtin_fminf(__builtin_fminf(tcx + hx, tcy + hy), tcz + hz);
     return (tmax >= __builtin_fmaxf(tmin, 0.0f)) && (tmin <= c.best);
+}
+PT_DEV float half_lo(float packed) {  // the f16 in the low / high half of a record word, as f32 (exact)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(f32_bits(packed) & 0xffffu));
+#else
+    return half_bits_to_float(f32_bits(packed) & 0xffffu);
+#endif
+}
+PT_DEV float half_hi(float packed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(f32_bits(packed) >> 16));
+#else
+    return half_bits_to_float(f32_bits(packed) >> 16);
+#endif
 }
 // An empty stack hands the traversal to the next climb record (kCursorDone when there is none: a traversal from the root,
 // or a climb that has reached it).  c.up is not cleared here: the record it names overwrites it when it is stepped.
@@ -445,11 +475,12 @@ PT_DEV int cursor_pop(LbvhCursor& c, const int* stack, uint32_t stride) {
 // farther; with none hit, pops.  Afterwards c.cur is a record, a leaf (< 0) or kCursorDone.
 template <bool STATS>
 PT_DEV void cursor_inner_step(const LbvhView& v, LbvhCursor& c, int* stack, uint32_t stride, uint32_t& node_visits) {
-    const size_t at = 4 * (size_t)c.cur;
-    const float4 n0 = v.wide[at], n1 = v.wide[at + 1], n2 = v.wide[at + 2], n3 = v.wide[at + 3];
+    const size_t at = 3 * (size_t)c.cur;  // 48-byte records (lbvh.h)
+    const float4 n0 = v.wide[at], n1 = v.wide[at + 1], n2 = v.wide[at + 2];
     if (STATS) node_visits += 2;  // two box tests
     float tl, tr;
-    const bool hl = padded_box_hit(c, n0, n1, tl), hr = padded_box_hit(c, n2, n3, tr);
+    const bool hl = padded_box_hit(c, mk3(n0.x, n0.y, n0.z), mk3(half_lo(n2.x), half_hi(n2.x), half_lo(n2.y)), tl);
+    const bool hr = padded_box_hit(c, mk3(n1.x, n1.y, n1.z), mk3(half_hi(n2.y), half_lo(n2.z), half_hi(n2.z)), tr);
     const int rl = __builtin_bit_cast(int, n0.w), rr = __builtin_bit_cast(int, n1.w);
     // a climb record: the same two box tests (sibling and uncle subtrees), and it names the record two levels up in the
     // word a wide node leaves zero (no record has index 0).  Deciding on the loaded word keeps this ONE 16-byte load: a

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
 #define IR_SHADE_BATCH 32
 #endif
 #ifndef IR_STEPS_PER_ROUND
-#define IR_STEPS_PER_ROUND 4
+#define IR_STEPS_PER_ROUND 3
 #endif
 constexpr uint32_t kShadeBatch = IR_SHADE_BATCH;         // run the shading block when this many lanes wait for it
 constexpr uint32_t kStepsPerRound = IR_STEPS_PER_ROUND;  // traversal steps between two looks at the wave's state
@@ -744,8 +744,9 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
         }
         // Two node steps per leaf step: lanes that stay on inner nodes (most of them) descend two levels for every pass
         // of the divergent leaf code, which then finds more lanes waiting for it (+7 % on C3 over one-and-one; three
-        // node steps or a majority vote between the two kinds of step measured no better).  Four such steps between two
-        // looks at the wave's state (8 was right while lanes owned pixels; with tasks, refilling sooner is +3 %).
+        // node steps or a majority vote between the two kinds of step measured no better).  Three such steps between two
+        // looks at the wave's state (8 was right while lanes owned pixels, 4 with tasks; with traversals that start at
+        // their leaf and are shorter, 3: +1.6 %, 2 the same, 6 -1 %).
         for (uint32_t k = 0; k < kStepsPerRound; ++k) {
             if (traversing) {
                 if (cur.cur >= 0) { profile(2); cursor_inner_step<STATS>(a.bvh, cur, stack, 256u, wc.nodes); }

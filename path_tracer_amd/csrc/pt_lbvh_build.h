@@ -27,7 +27,7 @@ size_t lbvh_build_scratch_bytes(uint32_t n);
 hipError_t lbvh_build_device(const float4* d_spheres, uint32_t n, void* scratch, size_t scratch_bytes, float4* d_leaf_spheres,
                              int* d_leaf_index, LbvhDeviceTree* tree, bool refit, hipStream_t stream);
 
-// Wide nodes in pre-order, then the climb records (lbvh.h), into d_wide (room for 2 (n - 1) + n records of 64 bytes, zeroed
+// Wide nodes in pre-order, then the climb records (lbvh.h), into d_wide (room for 2 (n - 1) + n records of 48 bytes, zeroed
 // by the caller: slots no node owns stay zero); the traversal start of every sphere into d_sphere_start (n x int2, by
 // original index); fills info[6] and info[7].
 hipError_t lbvh_emit_device(const float4* d_spheres, uint32_t n, const LbvhDeviceTree& tree, float4* d_wide, int2* d_sphere_start,

@@ -13,7 +13,7 @@
 //   lb_boxes / lb_boxes_top      bottom-up: the second child to arrive at a node unions the two boxes (left, right
 //                                order, so the zero signs match the host's too) and counts the node's inner nodes;
 //                                nodes inside one workgroup's positions first, the straddling ones in one workgroup
-//   lb_emit                      nodes of >= 3 spheres become 64-byte wide nodes, numbered in pre-order: a node's
+//   lb_emit                      nodes of >= 3 spheres become 48-byte wide nodes, numbered in pre-order: a node's
 //                                rank is the sum over its ancestors of 1 + (inner nodes of the left sibling subtree);
 //                                the same thread writes the climb records of the node's two children (lbvh.h) and the
 //                                traversal start of the spheres in its leaf children
@@ -293,15 +293,13 @@ __device__ __forceinline__ void child_entry(const float4* __restrict__ spheres, 
     *ref = count <= (int)kLeafMax ? -(lo * 8 + count) - 1 : rank;
 }
 
-// One climb record (lbvh.h "Climb records"): `sib` = the other child of the node's parent, `unc` = the other child of its
-// grandparent (has_uncle == false: the parent is the root).
-__device__ __forceinline__ void put_climb(float4* __restrict__ rec, const Box& sib, int sib_ref, bool has_uncle, const Box& unc, int unc_ref,
-                                          int next) {
-    const float nan = __uint_as_float(0x7fc00000u);  // the host build's quiet NaN: a box no ray hits
-    rec[0] = make_float4(sib.lo[0], sib.lo[1], sib.lo[2], __int_as_float(sib_ref));
-    rec[1] = make_float4(sib.hi[0], sib.hi[1], sib.hi[2], __int_as_float(has_uncle ? unc_ref : -1));
-    rec[2] = has_uncle ? make_float4(unc.lo[0], unc.lo[1], unc.lo[2], __int_as_float(next)) : make_float4(nan, nan, nan, __int_as_float(next));
-    rec[3] = has_uncle ? make_float4(unc.hi[0], unc.hi[1], unc.hi[2], 0.0f) : make_float4(nan, nan, nan, 0.0f);
+// One 48-byte record (lbvh.h): boxes A and B as centre + f16 half extent, their refs, the next record.
+__device__ __forceinline__ void put_record(float4* __restrict__ rec, const Box& a, int a_ref, const Box* b, int b_ref, int next) {
+    uint32_t w[12];
+    pack_record(a.lo, a.hi, a_ref, b ? b->lo : nullptr, b ? b->hi : nullptr, b_ref, next, w);
+    rec[0] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+    rec[1] = make_float4(__uint_as_float(w[4]), __uint_as_float(w[5]), __uint_as_float(w[6]), __uint_as_float(w[7]));
+    rec[2] = make_float4(__uint_as_float(w[8]), __uint_as_float(w[9]), __uint_as_float(w[10]), __uint_as_float(w[11]));
 }
 
 __global__ void __launch_bounds__(kBlock) lb_emit(const float4* __restrict__ spheres, const uint32_t* __restrict__ order, int n,
@@ -325,11 +323,7 @@ __global__ void __launch_bounds__(kBlock) lb_emit(const float4* __restrict__ sph
     int rl, rr;
     child_entry(spheres, order, boxes, nd.x, nd.z, nd.z, rank + 1, &bl, &rl);
     child_entry(spheres, order, boxes, nd.z + 1, nd.y, nd.z + 1, rank + 1 + left_inner, &br, &rr);
-    float4* w = wide + 4 * (size_t)rank;
-    w[0] = make_float4(bl.lo[0], bl.lo[1], bl.lo[2], __int_as_float(rl));
-    w[1] = make_float4(bl.hi[0], bl.hi[1], bl.hi[2], __int_as_float(rr));
-    w[2] = make_float4(br.lo[0], br.lo[1], br.lo[2], 0.0f);
-    w[3] = make_float4(br.hi[0], br.hi[1], br.hi[2], 0.0f);
+    put_record(wide + 3 * (size_t)rank, bl, rl, &br, rr, 0);
     atomicMax(&info[6], (uint32_t)depth + 1u);  // the children are one level below
     const int n_inner = __float_as_int(boxes[0].w);
     if (i == 0) info[7] = (uint32_t)n_inner;
@@ -350,8 +344,8 @@ __global__ void __launch_bounds__(kBlock) lb_emit(const float4* __restrict__ sph
     }
     const int rec_l = rl >= 0 ? n_inner + rl : 2 * n_inner + nd.x;
     const int rec_r = rr >= 0 ? n_inner + rr : 2 * n_inner + nd.z + 1;
-    put_climb(wide + 4 * (size_t)rec_l, br, rr, has_uncle, bu, ru, next);
-    put_climb(wide + 4 * (size_t)rec_r, bl, rl, has_uncle, bu, ru, next);
+    put_record(wide + 3 * (size_t)rec_l, br, rr, has_uncle ? &bu : nullptr, has_uncle ? ru : -1, next);
+    put_record(wide + 3 * (size_t)rec_r, bl, rl, has_uncle ? &bu : nullptr, has_uncle ? ru : -1, next);
     if (rl < 0)
         for (int j = nd.x; j <= nd.z; ++j) sphere_start[order[j]] = make_int2(rl, rec_l);
     if (rr < 0)

@@ -142,10 +142,10 @@ class RayTracer:
         return {"builder": b.value, "seconds": t.value}
 
     def download_accel(self):
-        """LBVH arrays as built: (nodes, 16) f32 wide nodes (refs are int32 bit patterns), (n, 4) leaf spheres, (n,) indices."""
+        """LBVH arrays as built: (nodes, 12) f32 wide nodes (48-byte records) (refs are int32 bit patterns), (n, 4) leaf spheres, (n,) indices."""
         info = self.get_accel_info()
         n = getattr(self, "_n_spheres", 0)
-        wide = np.zeros((info["nodes"], 16), dtype=np.float32)
+        wide = np.zeros((info["nodes"], 12), dtype=np.float32)
         leaf = np.zeros((n, 4), dtype=np.float32)
         index = np.zeros((n,), dtype=np.int32)
         _capi.check(self._ctx, _capi.lib.ir_download_accel(self._ctx, wide.ctypes.data_as(C.c_void_p), info["nodes"], _capi.fptr(leaf),
@@ -153,11 +153,11 @@ class RayTracer:
         return wide, leaf, index
 
     def download_accel_climb(self):
-        """The LBVH's climb records ((nodes + n, 16) f32, refs are int32 bit patterns) and the per-sphere traversal start
+        """The LBVH's climb records ((nodes + n, 12) f32, refs are int32 bit patterns) and the per-sphere traversal start
         ((n, 2) int32: leaf ref, record), lbvh.h "Climb records"."""
         info = self.get_accel_info()
         n = getattr(self, "_n_spheres", 0)
-        rec = np.zeros((info["nodes"] + n, 16), dtype=np.float32)
+        rec = np.zeros((info["nodes"] + n, 12), dtype=np.float32)
         start = np.zeros((n, 2), dtype=np.int32)
         _capi.check(self._ctx, _capi.lib.ir_download_accel_climb(self._ctx, rec.ctypes.data_as(C.c_void_p), info["nodes"] + n,
                                                                  start.ctypes.data_as(_capi.c_i32_p), n))
