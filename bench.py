@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 W, H, SPP, BOUNCES, RR = 1920, 1080, 1024, 8, 2
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
 NOFMA_CEILING_TFLOPS = 78.6    # the same issue rate with one flop per lane-op (mul/add, no FMA contraction)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def flops_per_sample(st, ast=None):
@@ -43,6 +44,25 @@ def flops_per_sample(st, ast=None):
     else:
         total += 25 * ast["bvh_leaf_tests"] + 24 * ast["bvh_node_visits"]
     return total / samples
+
+
+def executed_flops_per_step(st, pst, n_spheres, spp, launches, ast=None):
+    """Flops the launches of one step really executed, in SURVEY 8d's units.  flops_per_sample charges every sample its
+    own primary ray, primary closest hit and (for a pixel that sees the sky) sky lookup, as the reference runs them; the
+    kernels evaluate those once per pixel and launch (no random input, pinhole_camera.rs:81-84) and finish a sky pixel
+    with four adds per sample.  pst = ir_get_primary_stats (once per pixel and launch)."""
+    samples = st["samples"]
+    alg = flops_per_sample(st, ast) * samples
+    pixels_l, path_l, d0_l = pst["pixels"], pst["path_pixels"], pst["primary_disc_pos"]
+    per_launch = spp / launches              # samples a launch adds to each pixel
+    sky_l = pixels_l - path_l
+    saved = 36.0 * (samples - pixels_l)                                  # ray generation
+    if ast is None:
+        saved += 25.0 * n_spheres * (samples - pixels_l)                 # the primary scan (the tree's work is counted as executed already)
+    saved += 5.0 * d0_l * (per_launch - 1.0)                             # its disc >= 0 tests
+    saved += 22.0 * path_l * (per_launch - 1.0)                          # closest_hit of the primary hit
+    saved += sky_l * (25.0 * per_launch - (21.0 + 4.0 * per_launch))     # sky pixels: one lookup, four adds per sample
+    return alg - saved
 
 
 def host_cpu():
@@ -137,6 +157,11 @@ def main():
                     help="N > 1 only. native (default): the library's RCCL step (ir_comm_init / ir_combine_async), overlapped "
                          "with the next render; falls back to torch if RCCL cannot be initialised. torch: torch.distributed "
                          "reduce of the accumulator tensors on the render stream.")
+    ap.add_argument("--sky-size", default=None, metavar="WxH",
+                    help="size of the synthetic equirect sky (default 1024x512 = 8 MB on the device, cache-resident); 8192x4096 "
+                         "is 537 MB as float4, twice the Infinity Cache: every lookup of an escaping path is an HBM access")
+    ap.add_argument("--sky-filter", choices=["nearest", "bilinear"], default="nearest",
+                    help="nearest = the reference (exr.rs:20-23) and the metric's; bilinear = north_star's variant (ir_set_sky_filter)")
     ap.add_argument("--sample-block", type=int, default=None,
                     help="ir_set_sample_block; default: IR_SAMPLE_BLOCK_AUTO (0), which is the library default of 128 on C2, C4 and C5 "
                          "and 64 on C3 (config.sample_block says what the run used)")
@@ -174,18 +199,23 @@ def main():
     import path_tracer_amd as pta
     from path_tracer_amd import _capi, workloads as Wk
 
+    sky_w, sky_h = 1024, 512
+    if args.sky_size:
+        sky_w, sky_h = (int(v) for v in args.sky_size.lower().split("x"))
+    sky_note = f"synthetic {sky_w}x{sky_h} equirect sky ({sky_w * sky_h * 16 / 1e6:.0f} MB on the device), {args.sky_filter} lookup"
+
     global W, H
     if args.workload == "c4":
         W, H = 3840, 2160
         spp = args.spp or 4096
-        scene = Wk.scene_s1()
+        scene = Wk.scene_s1(skybox=Wk.synthetic_sky(sky_w, sky_h))
         cam = Wk.default_camera(W, H)
-        wl_name = f"C4: scene S1 default+emitter + synthetic sky, {W}x{H}, {spp} spp"
+        wl_name = f"C4: scene S1 default+emitter + {sky_note}, {W}x{H}, {spp} spp"
     elif args.workload == "c5":
         spp = args.spp or 65536
-        scene = Wk.scene_s1(emitter=False, skybox=Wk.synthetic_sky(sun_scale=4000.0))
+        scene = Wk.scene_s1(emitter=False, skybox=Wk.synthetic_sky(sky_w, sky_h, sun_scale=4000.0))
         cam = Wk.default_camera(W, H)
-        wl_name = f"C5: scene S1 without emitter, sun-dominated synthetic sky, {W}x{H}, {spp} spp per GPU"
+        wl_name = f"C5: scene S1 without emitter, sun-dominated {sky_note}, {W}x{H}, {spp} spp per GPU"
     elif args.workload == "c3":
         spp = args.spp or 256
         scene = Wk.scene_s2()
@@ -193,15 +223,16 @@ def main():
         wl_name = f"C3: scene S2 (10 000 random Lambertian/emissive spheres, constant sky), {W}x{H}, {spp} spp per GPU"
     else:
         spp = args.spp or SPP
-        scene = Wk.scene_s1()
+        scene = Wk.scene_s1(skybox=Wk.synthetic_sky(sky_w, sky_h))
         cam = Wk.default_camera(W, H)
-        wl_name = f"C2: scene S1 default+emitter (3 spheres) + synthetic 1024x512 equirect sky, {W}x{H}, {spp} spp per GPU"
+        wl_name = f"C2: scene S1 default+emitter (3 spheres) + {sky_note}, {W}x{H}, {spp} spp per GPU"
     rt = pta.RayTracer(0, 0, device=local_rank)
     rt.set_active_camera(cam)
     rt.set_integrator(bounces=BOUNCES, max_compulsory_bounces=RR, seed=Wk.RNG_SEED)
     rt.set_schedule({"auto": _capi.IR_SCHEDULE_AUTO, "regeneration": _capi.IR_SCHEDULE_REGENERATION,
                      "wavefront": _capi.IR_SCHEDULE_WAVEFRONT}[args.schedule])
     rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
+    rt.set_sky_filter(_capi.IR_SKY_BILINEAR if args.sky_filter == "bilinear" else _capi.IR_SKY_NEAREST)
     rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
     rt.set_sample_block(args.sample_block if args.sample_block is not None else _capi.IR_SAMPLE_BLOCK_AUTO)
     partition = args.partition or ("tiles" if args.workload == "c4" else "samples")
@@ -352,20 +383,45 @@ def main():
         samples_per_launch = W * H * spp / launches_per_step / (world if partition == "tiles" else 1)
         achieved = samples_per_launch * F / (avg_launch_ms * 1e-3) / 1e12
         total_samples = work_ranks * W * H * spp * args.steps
-        # Counter-derived figures of this same launch (C2 at 1024 spp) from the round's committed rocprofv3 PMC passes
-        # (profiles/r2_pmc_roofline.json, written by tools/pmc_summary.py --json from tools/gpu_profile.sh's passes over
-        # the tree that is benchmarked): HBM-side bytes, lane utilisation, executed FP instruction mix.  Rates are formed
-        # with the launch duration measured live above.
-        traffic = lane_util = executed_tf = pmc_source = None
-        tpath = os.path.join(ROOT, "profiles", "r2_pmc_roofline.json")
-        if args.workload == "c2" and spp == SPP and not lbvh and BOUNCES == 8 and os.path.exists(tpath):
+        pst = rt.get_primary_stats()
+        n_spheres = len(scene.flat_spheres()[1])
+        executed_flops = executed_flops_per_step(st, pst, n_spheres, spp, launches_per_step, ast)
+        # algorithmic bytes of one launch: accumulator read-modify-write 40 B per pixel, block sums written by the
+        # path kernel and read by the merge (16 B each way per task), one texel per executed sky lookup (16 B as float4;
+        # bilinear: four of them)
+        per_launch = spp / launches_per_step
+        n_blocks = -(-int(per_launch) // rt.get_sample_block(W, H, spp))
+        sky_pixels = (pst["pixels"] - pst["path_pixels"]) / launches_per_step
+        lookups = ((st["traces"] - st["hits"]) / launches_per_step - sky_pixels * per_launch + sky_pixels) if scene.skybox is not None else 0.0
+        texel_bytes = 64 if args.sky_filter == "bilinear" else 16
+        algorithmic_bytes = (W * H * 40.0 + (pst["path_pixels"] / launches_per_step) * n_blocks * 32.0 * (n_blocks > 1)
+                             + lookups * texel_bytes)
+        # Counter-derived figures of this workload's launch from the round's committed rocprofv3 PMC passes
+        # (profiles/r3_pmc_roofline_<workload>.json, written by tools/pmc_summary.py --json from tools/pmc_passes.sh over
+        # the tree that is benchmarked): bytes at the L2's far side, lane utilisation, executed FP instruction mix, and
+        # which limit the launch runs into.  Rates are formed with the launch duration measured live above.
+        traffic = lane_util = executed_tf = pmc_source = l2_hit = None
+        bound = "valu"
+        key = args.workload + ("" if (sky_w, sky_h, args.sky_filter) == (1024, 512, "nearest") else f"_sky{sky_w}x{sky_h}_{args.sky_filter}")
+        tpath = os.path.join(ROOT, "profiles", f"r3_pmc_roofline_{key}.json")
+        pmc_launch_spp = {"c2": 1024, "c3": 256, "c4": 4096, "c5": 4096}  # samples per pixel of the launch the passes profiled
+        if per_launch == pmc_launch_spp[args.workload] and BOUNCES == 8 and args.sky_sampling == "bsdf" and os.path.exists(tpath):
             with open(tpath) as f:
                 pmc = json.load(f)
             traffic = pmc.get("traffic_bytes_per_launch")
             lane_util = pmc.get("lane_utilisation")
+            l2_hit = pmc.get("l2_hit_rate")
+            bound = pmc.get("bound", "valu")
             if pmc.get("executed_flop_per_launch"):
                 executed_tf = pmc["executed_flop_per_launch"] / (avg_launch_ms * 1e-3) / 1e12
             pmc_source = pmc.get("source")
+        hbm_gbs = algorithmic_bytes / (avg_launch_ms * 1e-3) / 1e9
+        if bound == "hbm":
+            roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+                    "valu_achieved_tflops": achieved, "valu_frac": achieved / PEAK_FP32_VALU_TFLOPS}
+        else:
+            roof = {"bound": bound, "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_VALU_TFLOPS, "algorithmic_gbs": hbm_gbs}
         out = {
             "metric": "Msamples/sec (path samples, max depth 8) at 1920x1080",
             "value": total_samples / elapsed / 1e6,
@@ -389,15 +445,16 @@ def main():
                 "sample_block": rt.get_sample_block(W, H, spp),
             },
             "roofline": {
-                "bound": "valu",
-                "achieved": achieved,
-                "peak": PEAK_FP32_VALU_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                **roof,
+                # flops all three kernels of a launch really executed (primary ray and primary closest hit once per pixel and
+                # launch, sky pixels four adds per sample) / the launch sequence's device time / the FP32 vector peak
+                "frac_executed": executed_flops / launches_per_step / (avg_sequence_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                "executed_flops_per_sample": executed_flops / st["samples"],
+                "algorithmic_bytes_per_launch": algorithmic_bytes,
                 "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, separate --pmc passes); algorithmic: 40 B/pixel "
-                                "accumulator = 83 MB + 16 B per block sum and pixel + 16 B per escaping path from the "
-                                "L2/MALL-resident sky",
+                "traffic_unit": "bytes per launch at the L2's far side (FETCH_SIZE + WRITE_SIZE, separate --pmc passes): HBM "
+                                "plus what the 256 MB Infinity Cache served",
+                "l2_hit_rate": l2_hit,
                 "frac_of_nofma_ceiling": achieved / NOFMA_CEILING_TFLOPS,
                 "executed_fp_tflops": executed_tf,
                 "lane_utilisation": lane_util,

@@ -318,6 +318,12 @@ int ir_get_accel_stats(ir_context* ctx, uint64_t out2[2]);
  * roulette (bounce >= max_compulsory_bounces), hit geometry, sky lookup + sample commit.  LBVH integrator: rounds of the
  * wave loop (lanes with work left), shading block, inner-node steps, leaf steps. */
 int ir_get_lane_profile(ir_context* ctx, uint64_t out8[8]);
+/* What the launches of the same render executed of the per-pixel work: path pixels (the primary ray hit something),
+ * discriminant >= 0 tests of the primary traces, pixels — each counted once per pixel and launch.  ir_get_stats charges the
+ * primary ray to every sample, as the reference runs it (integrator.rs:40-51); the kernels evaluate it once per
+ * pixel and launch because it has no random input (pinhole_camera.rs:81-84), and finish a sky pixel with four adds per
+ * sample.  bench.py forms the executed flop count (roofline.frac_executed) from the two. */
+int ir_get_primary_stats(ir_context* ctx, uint64_t out3[3]);
 
 /* Self test of the arithmetic contract (no counterpart in the reference).  The kernels replace hipcc's long IEEE
  * f32 sqrt / divide expansions by short sequences that return the same correctly rounded bits; this runs, on the

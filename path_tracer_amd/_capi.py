@@ -131,6 +131,7 @@ PROTOTYPES = {
     "ir_get_stats": (C.c_int, [ctx_p, c_u64_p]),
     "ir_get_accel_stats": (C.c_int, [ctx_p, c_u64_p]),
     "ir_get_lane_profile": (C.c_int, [ctx_p, c_u64_p]),
+    "ir_get_primary_stats": (C.c_int, [ctx_p, c_u64_p]),
     "ir_selftest_exact_math": (C.c_int, [ctx_p, c_u64_p, C.c_uint32, C.c_uint32]),
     "ir_exr_load": (C.c_int, [C.c_char_p, C.POINTER(c_float_p), c_u32_p, c_u32_p]),
     "ir_exr_last_error": (C.c_char_p, []),

@@ -262,6 +262,25 @@ int ensure_sky_tables(ir_context* ctx) {
     return IR_OK;
 }
 
+// The bilinear lookup reads two image rows: 2.2 memory sectors per lookup on a sky no cache holds.  From this size on
+// (float4 texels; the Infinity Cache is 256 MB) a footprint table four times the image gives every lookup its four texels
+// in ONE 64-byte record (pt_device.h sky_bilinear_quad): HBM capacity (288 GB) spent on HBM accesses.
+constexpr size_t kSkyQuadFromBytes = 128ull << 20;
+bool wants_sky_quad(const ir_context* ctx) {
+    static const int forced = getenv("IR_DEBUG_SKY_QUAD") ? atoi(getenv("IR_DEBUG_SKY_QUAD")) : -1;  // tools/ A/B runs only
+    if (ctx->sky_filter != IR_SKY_BILINEAR || !ctx->d_skybox.p || !ctx->sky_w) return false;
+    if (forced >= 0) return forced != 0;
+    return (size_t)ctx->sky_w * ctx->sky_h * sizeof(float4) >= kSkyQuadFromBytes;
+}
+int ensure_sky_quad(ir_context* ctx) {
+    if (!wants_sky_quad(ctx) || ctx->sky_quad_valid) return IR_OK;
+    const size_t bytes = (size_t)(ctx->sky_h + 1) * ctx->sky_w * 4 * sizeof(float4);
+    IR_TRY(ensure(ctx, ctx->d_skyquad, bytes));
+    IR_HIP(ctx, pt::launch_sky_quad((const float4*)ctx->d_skybox.p, ctx->sky_w, ctx->sky_h, (float4*)ctx->d_skyquad.p, ctx->stream));
+    ctx->sky_quad_valid = true;
+    return IR_OK;
+}
+
 void fill_bvh(const ir_context* ctx, pt::LbvhView& v) {
     v.wide = (const float4*)ctx->d_bvh_nodes.p;
     v.leaf_spheres = (const float4*)ctx->d_bvh_spheres.p;
@@ -358,7 +377,7 @@ void ir_destroy(ir_context* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
-    release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_rays);
+    release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_skyquad); release(ctx->d_rays);
     if (ctx->h_argb) (void)hipHostFree(ctx->h_argb);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
     release(ctx->d_stats); release(ctx->d_partials);
@@ -445,9 +464,11 @@ int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h) {
     if (!ctx) return IR_EINVAL;
     IR_TRY(use_device(ctx));
     ctx->sky_tables_valid = false;
+    ctx->sky_quad_valid = false;
     if (!rgb) {
         IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         release(ctx->d_skybox);
+        release(ctx->d_skyquad);
         ctx->sky_w = ctx->sky_h = 0;
         return IR_OK;
     }
@@ -586,12 +607,14 @@ int prepare_scene(ir_context* ctx) {
     IR_TRY(ensure_bvh(ctx));
     const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
     if (skymis) IR_TRY(ensure_sky_tables(ctx));
+    IR_TRY(ensure_sky_quad(ctx));
     return IR_OK;
 }
 bool scene_is_prepared(const ir_context* ctx) {
     if (ctx->shade_dirty || !ctx->d_shade.p || !ctx->d_spheres.p) return false;
     if (selected_accel(ctx) == pt::kAccelLbvh && !ctx->bvh_valid) return false;
     const bool skymis = ctx->sky_sampling == IR_SKY_SAMPLING_MIS && ctx->d_skybox.p && ctx->sky_w;
+    if (wants_sky_quad(ctx) && !ctx->sky_quad_valid) return false;
     return !skymis || ctx->sky_tables_valid;
 }
 
@@ -671,6 +694,7 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     a.sky_w = ctx->sky_w;
     a.sky_h = ctx->sky_h;
     a.sky_filter = ctx->sky_filter;
+    a.skyquad = (wants_sky_quad(ctx) && ctx->sky_quad_valid) ? (const float4*)ctx->d_skyquad.p : nullptr;
     if (skymis) {
         a.sky_marginal = (const float*)ctx->d_sky_marginal.p;
         a.sky_cond = (const float*)ctx->d_sky_cond.p;
@@ -1095,6 +1119,18 @@ int ir_get_accel_stats(ir_context* ctx, uint64_t out2[2]) {
     IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out2[0] = tmp[5];
     out2[1] = tmp[6];
+    return IR_OK;
+}
+
+int ir_get_primary_stats(ir_context* ctx, uint64_t out3[3]) {
+    if (!ctx) return IR_EINVAL;
+    if (!out3) return fail(ctx, IR_EINVAL, "ir_get_primary_stats: NULL");
+    if (!ctx->stats_valid) return fail(ctx, IR_ESTATE, "ir_get_primary_stats: the last render did not collect statistics");
+    IR_TRY(use_device(ctx));
+    unsigned long long tmp[pt::kNumStats];
+    IR_HIP(ctx, hipMemcpyAsync(tmp, ctx->d_stats.p, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream));
+    IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; ++i) out3[i] = tmp[15 + i];
     return IR_OK;
 }
 

@@ -634,6 +634,25 @@ PT_DEV f3 sky_bilinear(const float4* __restrict__ sky, uint32_t sw, uint32_t sh,
     return top + (bot - top) * ty;
 }
 
+// The same lookup through the footprint table (pt_kernels.h RenderArgs::skyquad): record (iy + 1) * w + x0 holds the four
+// texels (y0,x0) (y0,x1) (y1,x0) (y1,x1) the lookup with that cell reads, 64 bytes = one memory sector.  A sky too large
+// for the caches costs a lookup one HBM access this way instead of the 2.2 the two image rows cost (measured on an
+// 8192 x 4096 sky: 56 -> 118 Gsamples/s on C5); same texels, same arithmetic, same bits.
+PT_DEV f3 sky_bilinear_quad(const float4* __restrict__ quad, uint32_t sw, uint32_t sh, f3 dir) {
+    float u, v, tx, ty;
+    sky_uv(dir, u, v);
+    const int ix = bilinear_cell(u, (float)sw, tx), iy = bilinear_cell(v, (float)sh, ty);
+    const int w = (int)sw, h = (int)sh;
+    int x0 = ix % w;
+    if (x0 < 0) x0 += w;
+    const int row = iy + 1 < 0 ? 0 : (iy + 1 > h ? h : iy + 1);  // iy in [-1, h - 1] for any finite v; NaN gives -1
+    const float4* rec = quad + 4 * ((size_t)row * sw + x0);
+    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+    const f3 top = mk3(a.x, a.y, a.z) + (mk3(b.x, b.y, b.z) - mk3(a.x, a.y, a.z)) * tx;
+    const f3 bot = mk3(c.x, c.y, c.z) + (mk3(d.x, d.y, d.z) - mk3(c.x, c.y, c.z)) * tx;
+    return top + (bot - top) * ty;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Sky importance sampling (IR_SKY_SAMPLING_MIS; extension, the reference samples the BSDF only).
 // The reference's hemisphere sample (sampler.rs:43-53) is (r cos, r sin, 1 - r), r = sqrt(r2), NOT normalised; its

@@ -28,6 +28,9 @@ struct RenderArgs {
     const float4* skybox;  // rgb padded to float4, row 0 first; nullptr => constant sky
     uint32_t sky_w, sky_h;
     int sky_filter;
+    // Footprint table of the bilinear lookup, or nullptr: (sky_h + 1) x sky_w records of four texels, 64 bytes each
+    // (pt_device.h sky_bilinear_quad).  The host builds it for skies that no cache holds (launch_sky_quad).
+    const float4* skyquad;
     // sky importance sampling tables (sky_distribution.h); all nullptr => BSDF sampling only, as the reference
     const float* sky_marginal;
     const float* sky_cond;
@@ -86,7 +89,8 @@ struct HitsArgs {
 // ---- helpers shared by the kernel translation units (pt_kernels.hip, pt_wavefront.hip)
 PT_DEV f3 sky_eval(const RenderArgs& a, f3 dir) {
     if (a.skybox) {
-        if (a.sky_filter == 1) return sky_bilinear(a.skybox, a.sky_w, a.sky_h, dir);  // IR_SKY_BILINEAR
+        if (a.sky_filter == 1)  // IR_SKY_BILINEAR
+            return a.skyquad ? sky_bilinear_quad(a.skyquad, a.sky_w, a.sky_h, dir) : sky_bilinear(a.skybox, a.sky_w, a.sky_h, dir);
         return sky_nearest(a.skybox, a.sky_w, a.sky_h, dir);
     }
     return mk3(a.sky[0], a.sky[1], a.sky[2]);
@@ -150,7 +154,10 @@ hipError_t launch_wavefront(const WfArgs& a, int accel, uint32_t per_batch, uint
 
 // All launchers enqueue on `stream` and return the HIP status of the launch.
 enum { kAccelLinear = 0, kAccelLbvh = 1 };
-constexpr uint32_t kNumStats = 15;  // samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests, 8 x lane profile
+// samples, traces, tests, disc>=0, hits, bvh node visits, bvh leaf tests, 8 x lane profile; then what the launches really
+// executed of the per-pixel work: [15] path pixels (primary ray hit), [16] disc >= 0 tests of the primary traces, [17] pixels —
+// each once per pixel and launch (the counts before them charge the primary ray to every sample, as the reference runs it)
+constexpr uint32_t kNumStats = 18;
 // Task queues of the persistent path kernels (pt_kernels.hip take_task): counters 128 bytes apart, two sets of them.
 #ifndef IR_TASK_QUEUES
 #define IR_TASK_QUEUES 16  // (tools/ build variants with other counts)
@@ -168,6 +175,8 @@ hipError_t launch_render(const RenderArgs& a, int accel, bool stats, hipStream_t
                          hipEvent_t paths_end = nullptr);
 hipError_t launch_primary_hits(const HitsArgs& a, int accel, hipStream_t stream);
 hipError_t launch_resolve(const float4* sum, const uint32_t* counts, uint32_t* argb, size_t n, hipStream_t stream);
+// footprint table of the bilinear sky lookup: quad must hold (h + 1) * w * 4 float4
+hipError_t launch_sky_quad(const float4* sky, uint32_t w, uint32_t h, float4* quad, hipStream_t stream);
 // exact-math self test (pt_selftest.hip): adds mismatch counts into d_bad[kNumSelftests] (zeroed by the caller)
 constexpr uint32_t kNumSelftests = 10;
 hipError_t launch_selftest(unsigned long long* d_bad, uint32_t log2_random, hipStream_t stream);

@@ -255,6 +255,9 @@ __global__ __launch_bounds__(WG) void primary_kernel(const RenderArgs a) {
     if (STATS) {  // executed acceleration-structure work of the shared primary trace: once per launch
         atomicAdd(&a.stats[5], (unsigned long long)wc0.nodes);
         atomicAdd(&a.stats[6], (unsigned long long)wc0.leaves);
+        if (hit) atomicAdd(&a.stats[15], 1ull);
+        if (a.bounces != 0) atomicAdd(&a.stats[16], (unsigned long long)wc0.disc);
+        atomicAdd(&a.stats[17], 1ull);
     }
 }
 
@@ -373,6 +376,11 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
             h0.idx = -1;
             uint32_t disc0 = 0;
             if (a.bounces != 0) h0 = trace_linear<STATS>(s_sph, a.n_spheres, r0.o, r0.d, disc0);
+            if (STATS) {  // (as primary_kernel counts them)
+                if (h0.idx >= 0) atomicAdd(&a.stats[15], 1ull);
+                atomicAdd(&a.stats[16], (unsigned long long)disc0);
+                atomicAdd(&a.stats[17], 1ull);
+            }
             if (h0.idx >= 0) {
                 hit_geometry(s_sph[h0.idx], r0.o, r0.d, h0.t, p0.pos, p0.nrm);
                 p0.idx = h0.idx;
@@ -857,7 +865,28 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
     }
 }
 
+// Footprint table of sky_bilinear (pt_device.h): record (row, x0), row = iy + 1 in [0, h], holds the texels of rows
+// y0 = clamp(row - 1), y1 = clamp(row) and columns x0, x1 = x0 + 1 (wrapping).
+__global__ __launch_bounds__(256) void sky_quad_kernel(const float4* __restrict__ sky, uint32_t w, uint32_t h, float4* __restrict__ quad) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)(h + 1) * w) return;
+    const uint32_t row = (uint32_t)(i / w), x0 = (uint32_t)(i % w);
+    const uint32_t x1 = (x0 + 1 == w) ? 0u : x0 + 1;
+    const uint32_t y0 = row == 0 ? 0u : row - 1, y1 = row > h - 1 ? h - 1 : row;
+    quad[4 * i + 0] = sky[(size_t)y0 * w + x0];
+    quad[4 * i + 1] = sky[(size_t)y0 * w + x1];
+    quad[4 * i + 2] = sky[(size_t)y1 * w + x0];
+    quad[4 * i + 3] = sky[(size_t)y1 * w + x1];
+}
+
 }  // namespace
+
+hipError_t launch_sky_quad(const float4* sky, uint32_t w, uint32_t h, float4* quad, hipStream_t stream) {
+    const size_t n = (size_t)(h + 1) * w;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sky_quad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sky, w, h, quad);
+    return hipGetLastError();
+}
 
 hipError_t init_kernels() {
     hipError_t e;

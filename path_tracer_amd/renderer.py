@@ -207,6 +207,12 @@ class RayTracer:
         _capi.check(self._ctx, _capi.lib.ir_get_accel_stats(self._ctx, out))
         return {"bvh_node_visits": int(out[0]), "bvh_leaf_tests": int(out[1])}
 
+    def get_primary_stats(self):
+        """Executed per-pixel work of the last statistics render, once per pixel and launch (ir_get_primary_stats)."""
+        out = (C.c_uint64 * 3)()
+        _capi.check(self._ctx, _capi.lib.ir_get_primary_stats(self._ctx, out))
+        return dict(zip(("path_pixels", "primary_disc_pos", "pixels"), [int(v) for v in out]))
+
     def get_lane_profile(self):
         """(wave executions, active lanes) of the path loop's top, roulette, hit-geometry and sky/commit sections."""
         out = (C.c_uint64 * 8)()

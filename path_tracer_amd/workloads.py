@@ -37,31 +37,38 @@ def _unit(seed, index, stream):
 
 def synthetic_sky(width=1024, height=512, seed=SKY_SEED, sun_scale=40.0, sun_dir=(0.35, 0.55, -0.75)):
     """Equirectangular HDR sky: smooth vertical gradient + one bright sun lobe + low-amplitude hash noise.
-    Row 0 is the zenith (+Y), as ExrImage::sample assumes (exr.rs:15-21)."""
-    ys = (np.arange(height, dtype=np.float64) + 0.5) / height
+    Row 0 is the zenith (+Y), as ExrImage::sample assumes (exr.rs:15-21).  Every texel is a function of its own (x, y),
+    so the image is evaluated in bands of rows: an 8192 x 4096 sky (403 MB as Vec<Vec3>; 537 MB padded to
+    float4 on the device, far beyond the 256 MB Infinity Cache) does not need several GB of f64 temporaries."""
+    out = np.empty((height, width, 3), dtype=np.float32)
     xs = (np.arange(width, dtype=np.float64) + 0.5) / width
-    theta = ys[:, None] * np.pi                      # v = theta / pi
     phi = xs[None, :] * 2.0 * np.pi - np.pi          # u = (phi + pi) / (2 pi)
-    dy = np.cos(theta) * np.ones_like(phi)
-    st = np.sin(theta)
-    dx = st * np.cos(phi)
-    dz = st * np.sin(phi)
-    t = 0.5 * (dy + 1.0)
     horizon = np.array([0.85, 0.80, 0.75])
     zenith = np.array([0.25, 0.45, 0.95])
     ground = np.array([0.18, 0.16, 0.14])
-    up = horizon[None, None, :] * (1.0 - t[..., None]) * 2.0 + zenith[None, None, :] * (2.0 * t[..., None] - 1.0)
-    down = ground[None, None, :] * (1.0 - 2.0 * t[..., None]) + horizon[None, None, :] * (2.0 * t[..., None])
-    img = np.where((t >= 0.5)[..., None], up, down)
     s = np.asarray(sun_dir, dtype=np.float64)
     s = s / np.linalg.norm(s)
-    c = np.clip(dx * s[0] + dy * s[1] + dz * s[2], 0.0, 1.0)
-    lobe = sun_scale * c ** 256 + 0.6 * c ** 8
-    img = img + lobe[..., None] * np.array([1.0, 0.92, 0.8])[None, None, :]
-    idx = np.arange(width * height, dtype=np.uint32).reshape(height, width)
-    noise = np.stack([_unit(seed, idx, k) for k in range(3)], axis=-1)
-    img = img * (0.97 + 0.06 * noise)
-    return ExrImage(img.astype(np.float32).reshape(-1, 3), width, height)
+    band = max(1, (1 << 19) // width)
+    for y0 in range(0, height, band):
+        y1 = min(height, y0 + band)
+        ys = (np.arange(y0, y1, dtype=np.float64) + 0.5) / height
+        theta = ys[:, None] * np.pi                  # v = theta / pi
+        dy = np.cos(theta) * np.ones_like(phi)
+        st = np.sin(theta)
+        dx = st * np.cos(phi)
+        dz = st * np.sin(phi)
+        t = 0.5 * (dy + 1.0)
+        up = horizon[None, None, :] * (1.0 - t[..., None]) * 2.0 + zenith[None, None, :] * (2.0 * t[..., None] - 1.0)
+        down = ground[None, None, :] * (1.0 - 2.0 * t[..., None]) + horizon[None, None, :] * (2.0 * t[..., None])
+        img = np.where((t >= 0.5)[..., None], up, down)
+        c = np.clip(dx * s[0] + dy * s[1] + dz * s[2], 0.0, 1.0)
+        lobe = sun_scale * c ** 256 + 0.6 * c ** 8
+        img = img + lobe[..., None] * np.array([1.0, 0.92, 0.8])[None, None, :]
+        idx = (np.arange(y0 * width, y1 * width, dtype=np.uint64).astype(np.uint32)).reshape(y1 - y0, width)
+        noise = np.stack([_unit(seed, idx, k) for k in range(3)], axis=-1)
+        img = img * (0.97 + 0.06 * noise)
+        out[y0:y1] = img.astype(np.float32)
+    return ExrImage(out.reshape(-1, 3), width, height)
 
 
 def default_camera(width, height):

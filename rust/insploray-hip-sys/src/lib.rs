@@ -80,6 +80,7 @@ extern "C" {
     pub fn ir_get_stats(ctx: *mut ir_context, out5: *mut u64) -> c_int;
     pub fn ir_get_accel_stats(ctx: *mut ir_context, out2: *mut u64) -> c_int;
     pub fn ir_get_lane_profile(ctx: *mut ir_context, out8: *mut u64) -> c_int;
+    pub fn ir_get_primary_stats(ctx: *mut ir_context, out3: *mut u64) -> c_int;
     pub fn ir_selftest_exact_math(ctx: *mut ir_context, out_mismatches: *mut u64, n_out: u32, log2_random_samples: u32) -> c_int;
     pub fn ir_exr_load(path: *const c_char, out_rgb: *mut *mut c_float, out_w: *mut u32, out_h: *mut u32) -> c_int;
     pub fn ir_exr_last_error() -> *const c_char;

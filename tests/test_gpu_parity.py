@@ -163,6 +163,33 @@ def test_bilinear_sky_bit_exact_same_stream(pta, tracer, oracle):
     assert rel_rmse(s, s_near) < 0.05     # ... but the image is the same sky
 
 
+@pytest.mark.parametrize("schedule", ["regeneration", "wavefront"])
+def test_bilinear_sky_footprint_table_whole_frame(pta, tracer, oracle, schedule):
+    """A sky of 128 MB or more (as float4) is looked up through the footprint table (four texels of a bilinear cell in one
+    64-byte record, pt_device.h sky_bilinear_quad): the whole frame, wrap-around columns and pole rows included, must
+    equal the oracle's bilinear lookup bit for bit; a camera that looks straight up and one that looks along the seam."""
+    from path_tracer_amd import _capi, workloads as W
+    from path_tracer_amd.cameras import PinholeCamera
+    w, h, spp = 96, 54, 24
+    scene = W.scene_s1(skybox=W.synthetic_sky(4096, 2048))   # 134 MB on the device
+    tracer.set_sky_filter(_capi.IR_SKY_BILINEAR)
+    tracer.set_schedule(_capi.IR_SCHEDULE_WAVEFRONT if schedule == "wavefront" else _capi.IR_SCHEDULE_REGENERATION)
+    oracle.set_sky_filter(1)
+    try:
+        for cam in (W.default_camera(w, h), PinholeCamera((0.0, 0.3, 2.0), (1.5707964, 0.0, 0.0), 35.0, 55.0, [w, h]),
+                    PinholeCamera((0.0, 0.2, 2.0), (0.0, 1.5707964, 0.0), 20.0, 55.0, [w, h])):
+            _setup(pta, tracer, scene, cam, 8, 2)
+            tracer.render(scene, w, h, False, spp=spp)
+            s, c = tracer.get_radiance()
+            os_, oc, _, _ = oracle.render(oracle.camera_from(cam, w, h), scene, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1)
+            assert np.array_equal(c, oc)
+            assert np.array_equal(s.view(np.uint32), os_.view(np.uint32)), f"max abs diff {np.abs(s - os_).max()}"
+    finally:
+        tracer.set_sky_filter(_capi.IR_SKY_NEAREST)
+        tracer.set_schedule(_capi.IR_SCHEDULE_AUTO)
+        oracle.set_sky_filter(0)
+
+
 def test_radiance_vs_libm_oracle_rel_rmse(pta, tracer, oracle):
     from path_tracer_amd import workloads as W
     w, h, spp = 320, 180, 64
