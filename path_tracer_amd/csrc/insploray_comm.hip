@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -61,7 +62,18 @@ const Rccl* rccl() {
         // A copy the process already holds (torch ships one under the same soname) is shared: RTLD_NOLOAD first.  A fresh
         // copy is loaded RTLD_LOCAL, so that its symbols never interpose on another RCCL that is loaded later.
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // IR_DEBUG_RCCL_LIB=<path>: tests only (like IR_DEBUG_LIB) — a stand-in transport with the same ten entry points
+        // (tests/cpp/fake_rccl.cpp), so that the N-rank branches below run on a box whose one GPU RCCL would refuse to share
+        if (const char* debug_lib = getenv("IR_DEBUG_RCCL_LIB")) {
+            r.handle = dlopen(debug_lib, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) {
+                const char* e = dlerror();
+                r.error = std::string("cannot load IR_DEBUG_RCCL_LIB ") + debug_lib + ": " + (e ? e : "?");
+                return;
+            }
+        }
         for (const char* n : names) {
+            if (r.handle) break;
             r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (r.handle) break;
         }
