@@ -51,6 +51,11 @@ enum { IR_SAMPLE_BLOCK_AUTO = 0 };  /* ir_set_sample_block */
 
 /* ABI version of this header (bumped on incompatible change). */
 uint32_t ir_abi_version(void);
+/* HIP_VERSION this library was compiled against and hipRuntimeGetVersion() of the runtime copy the process ended up with
+ * (major * 10000000 + minor * 100000 + patch).  A process that also holds PyTorch-ROCm runs on the runtime torch bundles
+ * (INTEGRATION.md section 3); the Python mirror warns when the two differ in their major version.  No counterpart in the
+ * reference (it has no device runtime). */
+int ir_hip_versions(int* out_compiled, int* out_runtime);
 
 /* -------------------------------------------------------------------------------------------------
  * Context.  Replaces RayTracer::new / Drop (renderer.rs:29-59, 182-191): where the reference spawns a
@@ -242,7 +247,9 @@ int ir_render(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, in
 int ir_render_async(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, int accumulate);
 int ir_synchronize(ir_context* ctx);
 /* ir_render_async into the CALLER's device buffers, allocating nothing.  No counterpart in the reference: it is for
- * callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc).  It is NOT a graph-capture entry
+ * point: every launch records timing events (ir_last_kernel_ms, ir_get_paths_kernel_history), and a recording of the call
+ * into a HIP graph has not been made to work (round 3 tried; a replay faulted) — enqueue it on a stream.
  * d_sum_rgba = width*height float4, d_counts = width*height u32, on the context's device; accumulate == 0 zeroes them
  * first and restarts the sample sequence at 0, otherwise the samples continue the context's sequence
  * (ir_samples_accumulated) as ir_render's would.  The context's own accumulator and size are not touched.  The block

@@ -70,7 +70,7 @@ inline V3 cross(V3 a, V3 b) {
 inline V3 normalize(V3 a) { return a * (1.0f / std::sqrt(dot(a, a))); }
 
 // ---------------------------------------------------------------------------------------------
-// math_mode 1: restatement of the device polynomial transcendentals (path_tracer_amd/csrc/pt_math.h).
+// math_mode 1: restatement of the device polynomial transcendentals (path_tracer_amd/csrc/pt_device.h, "Polynomial transcendentals").
 // Plain f32 + - * / only, no FMA: bit-reproducible between x86 SSE and gfx950 VALU.
 // sin/cos and acos use the classic single-precision Cephes minimax sets; atan2 is a one-divide form fitted in pt_device.h.
 // ---------------------------------------------------------------------------------------------
@@ -170,7 +170,7 @@ struct Sampler {
     }
 };
 
-// stream key = f(seed, pixel, sample): see path_tracer_amd/csrc/pt_rng.h for the product twin
+// stream key = f(seed, pixel, sample): see path_tracer_amd/csrc/pt_device.h ("Counter-based RNG") for the product twin
 inline uint32_t pixel_key(uint64_t seed, uint32_t pixel) { return mix32(pixel ^ (uint32_t)(seed & 0xffffffffu)); }
 inline uint32_t sample_key(uint64_t seed, uint32_t pkey, uint32_t sample) {
     return mix32(pkey + sample * 0x9e3779b9u + (uint32_t)(seed >> 32));

@@ -70,6 +70,7 @@ ctx_p = C.c_void_p
 # name -> (restype, argtypes); the single source the symbol-export test iterates over
 PROTOTYPES = {
     "ir_abi_version": (C.c_uint32, []),
+    "ir_hip_versions": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ir_create": (C.c_int, [C.POINTER(ctx_p), C.c_int]),
     "ir_destroy": (None, [ctx_p]),
     "ir_last_error": (C.c_char_p, [ctx_p]),
@@ -158,6 +159,29 @@ class InsplorayError(RuntimeError):
 def fptr(a):
     """float32 C-contiguous numpy array -> float*"""
     return a.ctypes.data_as(c_float_p)
+
+
+_runtime_checked = False
+
+
+def check_hip_runtime():
+    """Once per process, after the first context exists: the library was compiled by /opt/rocm's hipcc and may be running
+    on the HIP runtime PyTorch bundles (_share_torch_hip_runtime).  That works while the two agree in their major version;
+    a mismatch would otherwise surface as obscure registration or launch failures, so say it plainly."""
+    global _runtime_checked
+    if _runtime_checked:
+        return
+    _runtime_checked = True
+    compiled, runtime = C.c_int(0), C.c_int(0)
+    if lib.ir_hip_versions(C.byref(compiled), C.byref(runtime)) != IR_OK or runtime.value == 0:
+        return
+    if compiled.value // 10000000 != runtime.value // 10000000:
+        import warnings
+        warnings.warn("libinsploray_hip.so was built against HIP %d.%d but this process runs HIP runtime %d.%d (%s): set "
+                      "IR_SYSTEM_HIP_RUNTIME=1 and import torch first, or rebuild against the runtime in use" % (
+                          compiled.value // 10000000, compiled.value // 100000 % 100, runtime.value // 10000000,
+                          runtime.value // 100000 % 100, "PyTorch's bundled copy" if _torch_hip_runtime is not None else "already loaded"),
+                      RuntimeWarning, stacklevel=3)
 
 
 def check(ctx, rc):

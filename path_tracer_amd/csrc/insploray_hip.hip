@@ -336,7 +336,15 @@ int set_size(ir_context* ctx, uint32_t w, uint32_t h) {
 
 extern "C" {
 
-uint32_t ir_abi_version(void) { return 1; }
+uint32_t ir_abi_version(void) { return 3; }  // 3: round 3 (ir_download_accel_climb, ir_get_primary_stats, ir_hip_versions; 48-byte LBVH records)
+
+int ir_hip_versions(int* out_compiled, int* out_runtime) {
+    if (out_compiled) *out_compiled = HIP_VERSION;
+    int rt = 0;
+    const hipError_t e = hipRuntimeGetVersion(&rt);
+    if (out_runtime) *out_runtime = e == hipSuccess ? rt : 0;
+    return e == hipSuccess ? IR_OK : IR_EDEVICE;
+}
 
 const char* ir_last_global_error(void) { return g_global_error.c_str(); }
 

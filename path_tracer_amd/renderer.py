@@ -24,6 +24,7 @@ class RayTracer:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         self._ctx = _capi.ctx_p()
         _capi.check(None, _capi.lib.ir_create(C.byref(self._ctx), int(device)))
+        _capi.check_hip_runtime()
         self.device = int(device)
         self.active_camera = PinholeCamera((0.0, 0.0, 2.0), (0.0, 0.0, 0.0), 35.0, 55.0, [width, height])
         self.bounces = 5

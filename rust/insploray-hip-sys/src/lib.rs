@@ -16,6 +16,7 @@ pub const IR_COMM_ID_BYTES: usize = 128;
 
 extern "C" {
     pub fn ir_abi_version() -> u32;
+    pub fn ir_hip_versions(out_compiled: *mut c_int, out_runtime: *mut c_int) -> c_int;
     pub fn ir_create(out_ctx: *mut *mut ir_context, device: c_int) -> c_int;
     pub fn ir_destroy(ctx: *mut ir_context);
     pub fn ir_last_error(ctx: *const ir_context) -> *const c_char;

@@ -74,7 +74,7 @@ pub mod cameras {
         use glam::{Mat4, Vec3};
 
         /// pinhole_camera.rs:7-23.  The cached state is computed by ir_pinhole_compute, the same host code that the
-        /// tests pin against the reference's two camera tests (tests/test_camera.py).
+        /// tests pin against the reference's two camera tests (tests/test_oracle_camera.py).
         #[derive(Debug, Default)]
         pub struct PinholeCamera {
             pub position: Vec3,
@@ -553,7 +553,7 @@ pub mod renderer {
 #[cfg(test)]
 mod tests {
     //! The reference's two camera tests (pinhole_camera.rs:138-239) against this crate's PinholeCamera; they need the
-    //! shared library but no GPU.  tests/test_camera.py runs the same vectors through the same C functions.
+    //! shared library but no GPU.  tests/test_oracle_camera.py runs the same vectors through the same C functions.
     use super::cameras::{Camera, PinholeCamera};
     use glam::{Mat4, Vec3};
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} is declared in insploray_hip.h but not exported"
     assert sorted(_capi.PROTOTYPES) == declared_functions()
-    assert _capi.lib.ir_abi_version() == 1
+    assert _capi.lib.ir_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
