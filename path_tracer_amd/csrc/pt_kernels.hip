@@ -585,7 +585,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     // The task's state (pixel, block, samples done, block sum) is touched once per sample: it lives in LDS behind the
     // traversal stacks, not in 7 registers (80 VGPRs = 6 waves per SIMD is what this kernel lives on).  For the same
     // reason the shading point is not kept: the next ray's origin, pos + nrm * EPSILON (integrator.rs:80), goes straight
-    // into the cursor, and the pixel's primary-hit record is read again for every sample (an L1/L2 hit).
+    // into the cursor.  (The pixel's primary-hit record IS kept, see p0 below: the registers are there since the 48-byte
+    // records, and loads are what this kernel is short of.)
     uint32_t* const s_task = reinterpret_cast<uint32_t*>(s_dyn) + (size_t)a.bvh.stack_depth * 256 + threadIdx.x;
     auto task_word = [&](int k) -> uint32_t& { return s_task[k * 256]; };  // 0 list entry, 1 block, 2 samples done, 3..6 sum
     bool have = false, finished = false;
@@ -594,9 +595,14 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     int idx = 0;
     f3 contrib = mk3(1.0f, 1.0f, 1.0f), light = mk3(0.0f, 0.0f, 0.0f);
     LbvhCursor cur;
+    // The primary hit of the task's pixel stays in registers for the task's samples: reading the record again for every
+    // sample was two 16-byte loads through the L1 data path, which is what this kernel waits for (C3 +1.3 %).
+    PrimaryHit p0;
+    p0.pos = p0.nrm = mk3(0.0f, 0.0f, 0.0f);
+    p0.idx = 0;
+    p0.pixel = 0;
     auto restart = [&]() {  // a sample starts at the pixel's primary hit
         const uint32_t entry = task_word(0), blk = task_word(1), done = task_word(2);
-        const PrimaryHit p0 = load_primary(a, entry);
         b = 0;
         cur.o = p0.pos + p0.nrm * kEps;
         nrm = p0.nrm;
@@ -634,6 +640,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                 task_word(2) = 0u;
                 task_word(3) = task_word(4) = task_word(5) = task_word(6) = 0u;  // the block sum starts at +0
                 have = true;
+                p0 = load_primary(a, entry);
                 restart();
             }
             if (waiting && have) {
@@ -650,7 +657,9 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                         if (STATS) n_hits++;
                         f3 pos;
                         idx = cursor_hit_index(a.bvh, cur);
-                        hit_geometry(a.spheres[idx], cur.o, cur.d, cur.best, pos, nrm);
+                        // the centre out of the leaf-ordered array the winning test just read (same three floats as
+                        // a.spheres[idx]; hit_geometry takes nothing else): no load that waits for idx
+                        hit_geometry(a.bvh.leaf_spheres[cur.idx], cur.o, cur.d, cur.best, pos, nrm);
                         cur.o = pos + nrm * kEps;
                     } else {
                         if constexpr (SKYMIS) {
