@@ -400,7 +400,7 @@ def main():
         # (profiles/r3_pmc_roofline_<workload>.json, written by tools/pmc_summary.py --json from tools/pmc_passes.sh over
         # the tree that is benchmarked): bytes at the L2's far side, lane utilisation, executed FP instruction mix, and
         # which limit the launch runs into.  Rates are formed with the launch duration measured live above.
-        traffic = lane_util = executed_tf = pmc_source = l2_hit = None
+        traffic = lane_util = executed_tf = pmc_source = l2_hit = limiter = None
         bound = "valu"
         key = args.workload + ("" if (sky_w, sky_h, args.sky_filter) == (1024, 512, "nearest") else f"_sky{sky_w}x{sky_h}_{args.sky_filter}")
         tpath = os.path.join(ROOT, "profiles", f"r3_pmc_roofline_{key}.json")
@@ -415,6 +415,7 @@ def main():
             if pmc.get("executed_flop_per_launch"):
                 executed_tf = pmc["executed_flop_per_launch"] / (avg_launch_ms * 1e-3) / 1e12
             pmc_source = pmc.get("source")
+            limiter = pmc.get("limiter")
         hbm_gbs = algorithmic_bytes / (avg_launch_ms * 1e-3) / 1e9
         if bound == "hbm":
             roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
@@ -455,6 +456,7 @@ def main():
                 "traffic_unit": "bytes per launch at the L2's far side (FETCH_SIZE + WRITE_SIZE, separate --pmc passes): HBM "
                                 "plus what the 256 MB Infinity Cache served",
                 "l2_hit_rate": l2_hit,
+                "limiter": limiter,
                 "frac_of_nofma_ceiling": achieved / NOFMA_CEILING_TFLOPS,
                 "executed_fp_tflops": executed_tf,
                 "lane_utilisation": lane_util,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV passes for the path kernel:
-tools/pmc_summary.py gpurun_out/pmc_dir [kernel-substr] [--json out.json --source "text" --bound hbm|valu|l1]
+tools/pmc_summary.py gpurun_out/pmc_dir [kernel-substr] [--json out.json --source "text" --bound hbm|valu --limiter "text"]
 --json writes what bench.py's roofline object reads (profiles/r2_pmc_roofline.json): HBM-side bytes per launch
 (FETCH_SIZE + WRITE_SIZE, KB -> bytes), lane utilisation, executed FP32 operations per launch."""
 import csv
@@ -19,6 +19,11 @@ bound = None
 if "--bound" in args:  # which limit the launch runs into, decided by whoever read the counters ("hbm", "valu", "l1")
     i = args.index("--bound")
     bound = args[i + 1]
+    del args[i:i + 2]
+limiter = None
+if "--limiter" in args:  # one sentence: what the counters say the launch waits for
+    i = args.index("--limiter")
+    limiter = args[i + 1]
     del args[i:i + 2]
 if "--source" in args:
     i = args.index("--source")
@@ -67,7 +72,7 @@ if json_out:
            "fetch_size_kb": g("FETCH_SIZE"), "write_size_kb": g("WRITE_SIZE"),
            "traffic_bytes_per_launch": (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None else None,
            "l2_hit_rate": (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))) if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None else None,
-           "l2_miss_per_launch": g("TCC_MISS_sum"), "bound": bound or "valu",
+           "l2_miss_per_launch": g("TCC_MISS_sum"), "bound": bound or "valu", "limiter": limiter,
            "lane_utilisation": lane_util, "executed_flop_per_launch": executed,
            "valu_wave_instr_per_launch": g("SQ_INSTS_VALU"), "salu_wave_instr_per_launch": g("SQ_INSTS_SALU"),
            "note": "FETCH_SIZE / WRITE_SIZE count bytes at the L2's far side: HBM plus what the 256 MB Infinity Cache served. FETCH_SIZE is "
