@@ -269,6 +269,8 @@ constexpr size_t kSkyQuadFromBytes = 128ull << 20;
 bool wants_sky_quad(const ir_context* ctx) {
     static const int forced = getenv("IR_DEBUG_SKY_QUAD") ? atoi(getenv("IR_DEBUG_SKY_QUAD")) : -1;  // tools/ A/B runs only
     if (ctx->sky_filter != IR_SKY_BILINEAR || !ctx->d_skybox.p || !ctx->sky_w) return false;
+    // the table's records are addressed with 32-bit byte offsets: beyond 2^26 records the two-row lookup stays
+    if ((uint64_t)(ctx->sky_h + 1) * ctx->sky_w >= (1ull << 26)) return false;
     if (forced >= 0) return forced != 0;
     return (size_t)ctx->sky_w * ctx->sky_h * sizeof(float4) >= kSkyQuadFromBytes;
 }
@@ -481,6 +483,9 @@ int ir_set_skybox(ir_context* ctx, const float* rgb, uint32_t w, uint32_t h) {
         return IR_OK;
     }
     if (w == 0 || h == 0) return fail(ctx, IR_EINVAL, "ir_set_skybox: empty image %ux%u", w, h);
+    // the kernels address texels with 32-bit byte offsets and 24-bit row arithmetic (pt_device.h load16 / row_major)
+    if (w >= (1u << 24) || h >= (1u << 24) || (uint64_t)w * h >= (1ull << 28))
+        return fail(ctx, IR_ELIMIT, "ir_set_skybox: %ux%u exceeds the supported 2^28 texels (4 GiB as float4)", w, h);
     const size_t n = (size_t)w * h;
     std::vector<float> padded(n * 4);
     for (size_t i = 0; i < n; ++i) {

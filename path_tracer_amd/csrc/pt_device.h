@@ -575,13 +575,44 @@ PT_DEV f3 sample_hemisphere(f3 n, float r1, float r2) {
     return local.x * tangent + local.y * bitangent + local.z * n;
 }
 
+// Record `index` of a table of fewer than 2^28 16-byte records (the host checks the sizes at upload): a 32-bit byte offset
+// off the table's uniform base, i.e. one shift and a load with a scalar base where `base[index]` with a 64-bit index costs
+// three or four vector instructions of address arithmetic.
+PT_DEV float4 load16(const float4* __restrict__ base, uint32_t index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (uint32_t)(index << 4));
+#else
+    return base[index];
+#endif
+}
+// y * w + x for y, w < 2^24 (one full-rate v_mad_u32_u24)
+PT_DEV uint32_t row_major(uint32_t y, uint32_t w, uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (y & 0xffffffu) * (w & 0xffffffu) + x;  // the masks tell the compiler both factors fit 24 bits
+#else
+    return y * w + x;
+#endif
+}
+
 // ExrImage::sample, exr.rs:13-24 (nearest texel).  Texels are stored padded to float4.
 PT_DEV uint32_t texel_index(float f, uint32_t n) {
     // Rust: f.floor() as usize % n  (saturating cast: NaN / negative -> 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_u32_f32 is that cast: it truncates toward zero (= floor for f >= 0), gives 0 for NaN and for negatives and
+    // saturates above; the min keeps the host form's ceiling.  i >= n happens for u == 1 exactly (i == n) or never, so the
+    // remainder sits behind a wave-uniform branch instead of ten predicated instructions in every lookup.
+    uint32_t i;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(i) : "v"(f));
+    i = i < 4294967040u ? i : 4294967040u;
+    if (__builtin_expect(!wave_all(i < n), 0))
+        if (i >= n) i = i % n;
+    return i;
+#else
     f = __builtin_floorf(f);
     uint32_t i = (f > 0.0f) ? (uint32_t)__builtin_fminf(f, 4294967040.0f) : 0u;
     if (i >= n) i = i % n;
     return i;
+#endif
 }
 PT_DEV void sky_uv(f3 dir, float& u, float& v) {
     f3 d = normalize(dir);
@@ -604,7 +635,7 @@ PT_DEV f3 sky_nearest(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, 
     sky_uv(dir, u, v);
     uint32_t x = texel_index(u * (float)sw, sw);
     uint32_t y = texel_index(v * (float)sh, sh);
-    float4 t = sky[(size_t)y * sw + x];
+    float4 t = load16(sky, row_major(y, sw, x));
     return mk3(t.x, t.y, t.z);
 }
 
@@ -617,18 +648,26 @@ PT_DEV int bilinear_cell(float f, float n, float& frac) {
     frac = g - fl;
     return (fl >= -1.0f) ? (int)__builtin_fminf(fl, 1073741824.0f) : -1;  // NaN -> -1
 }
+// ix mod w in [0, w).  A lookup's cell index lies in [-1, w - 1] (u in [0, 1]), so the wave takes the one-add form
+// whenever every lane's index is within one period and the signed remainder (twenty instructions) otherwise.
+PT_DEV int wrap_column(int ix, int w) {
+    if (__builtin_expect(wave_all(ix >= -w && ix < w), 1)) return ix < 0 ? ix + w : ix;
+    int x0 = ix % w;
+    if (x0 < 0) x0 += w;
+    return x0;
+}
 PT_DEV f3 sky_bilinear(const float4* __restrict__ sky, uint32_t sw, uint32_t sh, f3 dir) {
     float u, v, tx, ty;
     sky_uv(dir, u, v);
     const int ix = bilinear_cell(u, (float)sw, tx), iy = bilinear_cell(v, (float)sh, ty);
     const int w = (int)sw, h = (int)sh;
-    int x0 = ix % w;
-    if (x0 < 0) x0 += w;
+    const int x0 = wrap_column(ix, w);
     const int x1 = (x0 + 1 == w) ? 0 : x0 + 1;
     const int y0 = iy < 0 ? 0 : (iy > h - 1 ? h - 1 : iy);
     const int y1 = iy + 1 < 0 ? 0 : (iy + 1 > h - 1 ? h - 1 : iy + 1);
-    const float4 a = sky[(size_t)y0 * sw + x0], b = sky[(size_t)y0 * sw + x1];
-    const float4 c = sky[(size_t)y1 * sw + x0], d = sky[(size_t)y1 * sw + x1];
+    const uint32_t r0 = row_major((uint32_t)y0, sw, 0u), r1 = row_major((uint32_t)y1, sw, 0u);
+    const float4 a = load16(sky, r0 + (uint32_t)x0), b = load16(sky, r0 + (uint32_t)x1);
+    const float4 c = load16(sky, r1 + (uint32_t)x0), d = load16(sky, r1 + (uint32_t)x1);
     const f3 top = mk3(a.x, a.y, a.z) + (mk3(b.x, b.y, b.z) - mk3(a.x, a.y, a.z)) * tx;
     const f3 bot = mk3(c.x, c.y, c.z) + (mk3(d.x, d.y, d.z) - mk3(c.x, c.y, c.z)) * tx;
     return top + (bot - top) * ty;
@@ -643,11 +682,10 @@ PT_DEV f3 sky_bilinear_quad(const float4* __restrict__ quad, uint32_t sw, uint32
     sky_uv(dir, u, v);
     const int ix = bilinear_cell(u, (float)sw, tx), iy = bilinear_cell(v, (float)sh, ty);
     const int w = (int)sw, h = (int)sh;
-    int x0 = ix % w;
-    if (x0 < 0) x0 += w;
+    const int x0 = wrap_column(ix, w);
     const int row = iy + 1 < 0 ? 0 : (iy + 1 > h ? h : iy + 1);  // iy in [-1, h - 1] for any finite v; NaN gives -1
-    const float4* rec = quad + 4 * ((size_t)row * sw + x0);
-    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+    const uint32_t rec = 4u * row_major((uint32_t)row, sw, (uint32_t)x0);  // < 2^28: the table is built for w * (h + 1) < 2^26
+    const float4 a = load16(quad, rec), b = load16(quad, rec + 1u), c = load16(quad, rec + 2u), d = load16(quad, rec + 3u);
     const f3 top = mk3(a.x, a.y, a.z) + (mk3(b.x, b.y, b.z) - mk3(a.x, a.y, a.z)) * tx;
     const f3 bot = mk3(c.x, c.y, c.z) + (mk3(d.x, d.y, d.z) - mk3(c.x, c.y, c.z)) * tx;
     return top + (bot - top) * ty;

@@ -434,8 +434,8 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
                 if (STATS) { n_traces++; n_disc += p0_disc; n_hits++; }
             }
             // ---- shade the hit of bounce b (integrator.rs:50-81)
-            const float4 m_brdf = a.shade[2 * idx];
-            const float4 m_emit = a.shade[2 * idx + 1];
+            const float4 m_brdf = load16(a.shade, 2u * (uint32_t)idx);
+            const float4 m_emit = load16(a.shade, 2u * (uint32_t)idx + 1u);
             light = light + mk3(m_emit.x, m_emit.y, m_emit.z) * contrib;
             const float r1 = draw(skey, 3 * b);
             const float r2 = draw(skey, 3 * b + 1);
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                         restart();
                     }
                     // shade the hit of bounce b (integrator.rs:50-81)
-                    const float4 m_brdf = a.shade[2 * idx];
-                    const float4 m_emit = a.shade[2 * idx + 1];
+                    const float4 m_brdf = load16(a.shade, 2u * (uint32_t)idx);
+                    const float4 m_emit = load16(a.shade, 2u * (uint32_t)idx + 1u);
                     // the next ray leaves sphere idx: its traversal starts at that sphere's leaf and climbs (lbvh.h)
                     const int2 start = a.bvh.sphere_start[idx];
                     light = light + mk3(m_emit.x, m_emit.y, m_emit.z) * contrib;

@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) void wf_bounce(const WfArgs a) {
         if (have) {
             const uint32_t skey = sample_key(a.r.seed_hi, pixel_key(a.r.seed_lo, p.pix), a.r.sample_base + a.batch_first + p.smp);
             // shade the hit of bounce b (integrator.rs:50-81)
-            const float4 m_brdf = a.r.shade[2 * p.idx];
-            const float4 m_emit = a.r.shade[2 * p.idx + 1];
+            const float4 m_brdf = load16(a.r.shade, 2u * (uint32_t)p.idx);
+            const float4 m_emit = load16(a.r.shade, 2u * (uint32_t)p.idx + 1u);
             p.light = p.light + mk3(m_emit.x, m_emit.y, m_emit.z) * p.contrib;
             const float r1 = draw(skey, 3 * b);
             const float r2 = draw(skey, 3 * b + 1);
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void wf_bounce_tree(const WfAr
                 } else {  // shade the hit of bounce b (integrator.rs:50-81)
                     fresh = false;
                     const uint32_t skey = sample_key(a.r.seed_hi, pixel_key(a.r.seed_lo, p.pix), a.r.sample_base + a.batch_first + p.smp);
-                    const float4 m_brdf = a.r.shade[2 * p.idx];
-                    const float4 m_emit = a.r.shade[2 * p.idx + 1];
+                    const float4 m_brdf = load16(a.r.shade, 2u * (uint32_t)p.idx);
+                    const float4 m_emit = load16(a.r.shade, 2u * (uint32_t)p.idx + 1u);
                     const int2 start = a.r.bvh.sphere_start[p.idx];  // the next ray starts at this sphere's leaf and climbs (lbvh.h)
                     p.light = p.light + mk3(m_emit.x, m_emit.y, m_emit.z) * p.contrib;
                     const float r1 = draw(skey, 3 * b);
