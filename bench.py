@@ -146,6 +146,8 @@ def main():
                          "sample indices, per-GPU spp fixed (weak scaling). tiles (default for c4): 64x64 tiles dealt "
                          "round-robin, total work fixed (strong scaling). Both end in one RCCL reduce(sum) to rank 0.")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
+    ap.add_argument("--accel-build", choices=["auto", "host", "device", "sah"], default="auto",
+                    help="LBVH builder (ir_set_accel_build); sah = host build with surface-area splits, for static scenes")
     ap.add_argument("--schedule", choices=["auto", "regeneration", "wavefront"], default="auto",
                     help="integrator schedule (ir_set_schedule); results are identical, only speed differs")
     ap.add_argument("--bounces", type=int, default=None,
@@ -234,6 +236,8 @@ def main():
     rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
     rt.set_sky_filter(_capi.IR_SKY_BILINEAR if args.sky_filter == "bilinear" else _capi.IR_SKY_NEAREST)
     rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
+    rt.set_accel_build({"auto": _capi.IR_BUILD_AUTO, "host": _capi.IR_BUILD_HOST, "device": _capi.IR_BUILD_DEVICE,
+                        "sah": _capi.IR_BUILD_HOST_SAH}[args.accel_build])
     rt.set_sample_block(args.sample_block if args.sample_block is not None else _capi.IR_SAMPLE_BLOCK_AUTO)
     partition = args.partition or ("tiles" if args.workload == "c4" else "samples")
     if world > 1:
@@ -438,7 +442,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{wl_name}, bounces {BOUNCES}, rr_start {RR}, "
-                            + (f"LBVH ({info['nodes']} nodes, depth {info['depth']})" if lbvh else "linear LDS scan"),
+                            + (f"LBVH ({info['nodes']} nodes, depth {info['depth']}, build {args.accel_build})" if lbvh else "linear LDS scan"),
                 "partition": "none" if world == 1 else (f"sample-range x{world}" if partition == "samples" else
                                                        f"64x64 tiles round-robin x{world}") + (" + RCCL reduce(sum) to rank 0" if partition == "samples" or native is None else " + RCCL gather of owned tiles to rank 0"),
                 "seed": hex(Wk.RNG_SEED),

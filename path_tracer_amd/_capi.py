@@ -55,7 +55,7 @@ IR_EINVAL, IR_EDEVICE, IR_ESTATE, IR_ENOMEM, IR_EIO, IR_ELIMIT = -1, -2, -3, -4,
 IR_SKY_NEAREST, IR_SKY_BILINEAR = 0, 1
 IR_PARTITION_NONE, IR_PARTITION_TILES, IR_PARTITION_SAMPLES = 0, 1, 2
 IR_ACCEL_AUTO, IR_ACCEL_LINEAR, IR_ACCEL_LBVH = 0, 1, 2
-IR_BUILD_AUTO, IR_BUILD_HOST, IR_BUILD_DEVICE, IR_BUILD_REFIT = 0, 1, 2, 3
+IR_BUILD_AUTO, IR_BUILD_HOST, IR_BUILD_DEVICE, IR_BUILD_REFIT, IR_BUILD_HOST_SAH = 0, 1, 2, 3, 4
 IR_SKY_SAMPLING_BSDF, IR_SKY_SAMPLING_MIS = 0, 1
 IR_SCHEDULE_AUTO, IR_SCHEDULE_REGENERATION, IR_SCHEDULE_WAVEFRONT = 0, 1, 2
 IR_SAMPLE_BLOCK_AUTO = 0

@@ -180,7 +180,8 @@ constexpr uint32_t kAutoDeviceBuildFrom = 2048;
 
 int build_bvh_host(ir_context* ctx) {
     pt::Lbvh t;
-    pt::build_lbvh(ctx->h_spheres.data(), ctx->n_spheres, t);
+    const bool sah = ctx->bvh_build == IR_BUILD_HOST_SAH;
+    pt::build_lbvh(ctx->h_spheres.data(), ctx->n_spheres, t, sah ? pt::LbvhSplit::Sah : pt::LbvhSplit::Morton);
     IR_TRY(upload(ctx, ctx->d_bvh_nodes, t.wide.data(), t.wide.size() * sizeof(pt::WideNode)));
     IR_TRY(upload(ctx, ctx->d_bvh_spheres, t.leaf_spheres.data(), t.leaf_spheres.size() * sizeof(float)));
     IR_TRY(upload(ctx, ctx->d_bvh_index, t.leaf_index.data(), t.leaf_index.size() * sizeof(int32_t)));
@@ -188,7 +189,7 @@ int build_bvh_host(ir_context* ctx) {
     ctx->bvh_nodes = t.n_inner;
     ctx->bvh_depth = t.max_depth;
     ctx->bvh_stack = t.stack_depth;
-    ctx->bvh_built_by = IR_BUILD_HOST;
+    ctx->bvh_built_by = sah ? IR_BUILD_HOST_SAH : IR_BUILD_HOST;
     return IR_OK;
 }
 
@@ -527,7 +528,7 @@ int ir_set_accel(ir_context* ctx, int accel) {
 
 int ir_set_accel_build(ir_context* ctx, int build) {
     if (!ctx) return IR_EINVAL;
-    if (build != IR_BUILD_AUTO && build != IR_BUILD_HOST && build != IR_BUILD_DEVICE && build != IR_BUILD_REFIT)
+    if (build != IR_BUILD_AUTO && build != IR_BUILD_HOST && build != IR_BUILD_DEVICE && build != IR_BUILD_REFIT && build != IR_BUILD_HOST_SAH)
         return fail(ctx, IR_EINVAL, "ir_set_accel_build: unknown mode %d", build);
     if (build != ctx->bvh_build) {
         ctx->bvh_valid = false;

@@ -20,8 +20,10 @@ uint32_t expand10(uint32_t v) {
     return v;
 }
 
+enum class Split { Morton, Median, Sah };
+
 struct Builder {
-    bool balanced = false;  // median splits only (depth <= log2(n) + 1): fallback when the Morton tree is too deep
+    Split mode = Split::Morton;  // Median (depth <= log2(n) + 1): fallback when the Morton tree is too deep; Sah: lbvh.h
     const float* s;
     std::vector<uint32_t> code;
     std::vector<uint32_t> order;
@@ -49,6 +51,82 @@ struct Builder {
         }
     }
 
+    // Binned surface-area heuristic over the sphere centres of order[first, last): 16 bins on each axis, cost of a plane =
+    // area(left boxes) * count(left) + area(right boxes) * count(right); order[first, last) is partitioned in place (stable,
+    // so the result is a function of the input alone) and the split position returned.  Spheres that are not finite, a
+    // range whose centres coincide, or a plane that leaves one side empty fall back to the median of the current order.
+    uint32_t sah_partition(uint32_t first, uint32_t last) {
+        constexpr int kBins = 16;
+        const uint32_t count = last - first, median = first + count / 2;
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = first; i < last; ++i) {
+            const float* p = s + 4 * (size_t)order[i];
+            for (int k = 0; k < 4; ++k)
+                if (!std::isfinite(p[k])) return median;
+            for (int k = 0; k < 3; ++k) {
+                clo[k] = std::min(clo[k], p[k]);
+                chi[k] = std::max(chi[k], p[k]);
+            }
+        }
+        struct Bin {
+            double lo[3], hi[3];
+            uint32_t n;
+        };
+        auto area = [](const double* lo, const double* hi) {
+            const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        double best_cost = INFINITY;
+        int best_axis = -1, best_bin = 0;
+        for (int axis = 0; axis < 3; ++axis) {
+            const float ext = chi[axis] - clo[axis];
+            if (!(ext > 0.0f)) continue;
+            Bin bins[kBins];
+            for (Bin& b : bins) {
+                for (int k = 0; k < 3; ++k) b.lo[k] = INFINITY, b.hi[k] = -INFINITY;
+                b.n = 0;
+            }
+            const double scale = (double)kBins / (double)ext;
+            for (uint32_t i = first; i < last; ++i) {
+                const float* p = s + 4 * (size_t)order[i];
+                const int j = std::min(kBins - 1, (int)(((double)p[axis] - (double)clo[axis]) * scale));
+                const double r = std::fabs((double)p[3]);
+                for (int k = 0; k < 3; ++k) {
+                    bins[j].lo[k] = std::min(bins[j].lo[k], (double)p[k] - r);
+                    bins[j].hi[k] = std::max(bins[j].hi[k], (double)p[k] + r);
+                }
+                bins[j].n++;
+            }
+            double right_area[kBins];
+            uint32_t right_n[kBins];
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t acc = 0;
+            for (int j = kBins - 1; j > 0; --j) {
+                for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], bins[j].lo[k]), hi[k] = std::max(hi[k], bins[j].hi[k]);
+                acc += bins[j].n;
+                right_area[j] = acc ? area(lo, hi) : 0.0;
+                right_n[j] = acc;
+            }
+            for (int k = 0; k < 3; ++k) lo[k] = INFINITY, hi[k] = -INFINITY;
+            acc = 0;
+            for (int j = 0; j + 1 < kBins; ++j) {  // plane between bin j and bin j + 1
+                for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], bins[j].lo[k]), hi[k] = std::max(hi[k], bins[j].hi[k]);
+                acc += bins[j].n;
+                if (acc == 0 || right_n[j + 1] == 0) continue;
+                const double cost = area(lo, hi) * acc + right_area[j + 1] * right_n[j + 1];
+                if (cost < best_cost) best_cost = cost, best_axis = axis, best_bin = j;
+            }
+        }
+        if (best_axis < 0) return median;
+        const double scale = (double)kBins / (double)(chi[best_axis] - clo[best_axis]);
+        auto mid = std::stable_partition(order.begin() + first, order.begin() + last, [&](uint32_t id) {
+            const float* p = s + 4 * (size_t)id;
+            return std::min(kBins - 1, (int)(((double)p[best_axis] - (double)clo[best_axis]) * scale)) <= best_bin;
+        });
+        const uint32_t split = (uint32_t)(mid - order.begin());
+        return (split == first || split == last) ? median : split;
+    }
+
     // returns the node index
     uint32_t build(uint32_t first, uint32_t last, uint32_t depth) {
         const uint32_t me = (uint32_t)out->nodes.size();
@@ -66,7 +144,9 @@ struct Builder {
             // and last key differ turns 1.  Equal codes continue on the bits of the sorted position.
             uint32_t split = first + count / 2;
             const uint32_t diff = code[order[first]] ^ code[order[last - 1]];
-            if (balanced) {
+            if (mode == Split::Sah) {
+                split = sah_partition(first, last);
+            } else if (mode == Split::Median) {
                 // median
             } else if (diff != 0) {
                 const int b = 31 - __builtin_clz(diff);
@@ -95,13 +175,13 @@ struct Builder {
 
 }  // namespace
 
-static void build_preorder(const float* spheres_xyzr, uint32_t n, Lbvh& out, bool balanced) {
+static void build_preorder(const float* spheres_xyzr, uint32_t n, Lbvh& out, Split mode) {
     out.nodes.clear();
     out.leaf_spheres.clear();
     out.leaf_index.clear();
     out.max_depth = 0;
     Builder b;
-    b.balanced = balanced;
+    b.mode = mode;
     b.s = spheres_xyzr;
     b.out = &out;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -145,7 +225,7 @@ static void build_preorder(const float* spheres_xyzr, uint32_t n, Lbvh& out, boo
     }
 }
 
-void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
+void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out, LbvhSplit split) {
     out.wide.clear();
     out.n_inner = 0;
     out.sphere_start.clear();
@@ -155,8 +235,8 @@ void build_lbvh(const float* spheres_xyzr, uint32_t n, Lbvh& out) {
     out.leaf_index.clear();
     out.max_depth = 0;
     if (n == 0) return;
-    build_preorder(spheres_xyzr, n, out, false);
-    if (out.max_depth + 1 > kMaxStack) build_preorder(spheres_xyzr, n, out, true);  // depth <= log2(n) + 1 <= 25
+    build_preorder(spheres_xyzr, n, out, split == LbvhSplit::Sah ? Split::Sah : Split::Morton);
+    if (out.max_depth + 1 > kMaxStack) build_preorder(spheres_xyzr, n, out, Split::Median);  // depth <= log2(n) + 1 <= 25
 
     // wide layout: inner nodes renumbered in pre-order; children of pre-order node i are i + 1 and nodes[i + 1].skip
     const size_t m = out.nodes.size();

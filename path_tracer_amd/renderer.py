@@ -134,7 +134,7 @@ class RayTracer:
         return {"accel": a.value, "nodes": n.value, "depth": d.value}
 
     def set_accel_build(self, build):
-        """IR_BUILD_AUTO / IR_BUILD_HOST / IR_BUILD_DEVICE: where the LBVH is (re)built after a scene edit."""
+        """IR_BUILD_AUTO / IR_BUILD_HOST / IR_BUILD_DEVICE / IR_BUILD_REFIT / IR_BUILD_HOST_SAH: where and how the LBVH is (re)built after a scene edit."""
         _capi.check(self._ctx, _capi.lib.ir_set_accel_build(self._ctx, int(build)))
 
     def get_accel_build_info(self):

@@ -32,10 +32,10 @@ static int32_t word(const pt::WideNode& w, int i) {
 
 // every reference of every record points at something that exists; every sphere is in exactly one leaf; every sphere's
 // traversal start is the leaf that holds it and that leaf's record
-static bool check_tree(const std::vector<float>& sph, const char* name) {
+static bool check_tree(const std::vector<float>& sph, const char* name, pt::LbvhSplit split) {
     const uint32_t n = (uint32_t)(sph.size() / 4);
     pt::Lbvh t;
-    pt::build_lbvh(sph.data(), n, t);
+    pt::build_lbvh(sph.data(), n, t, split);
     if (n == 0) {
         CHECK(t.wide.empty() && t.leaf_index.empty());
         std::printf("%-12s n=0 ok\n", name);
@@ -152,6 +152,10 @@ int main() {
         }
         return s;
     };
+    bool all = true;
+    for (pt::LbvhSplit split : {pt::LbvhSplit::Morton, pt::LbvhSplit::Sah}) {
+    auto check_tree = [&](const std::vector<float>& sph, const char* name) { return ::check_tree(sph, name, split); };
+    std::printf(split == pt::LbvhSplit::Sah ? "-- surface-area splits\n" : "-- Morton splits\n");
     for (uint32_t n : {0u, 1u, 2u, 3u, 4u, 5u, 7u, 64u, 1000u, 20000u}) ok = check_tree(random_scene(n), "random") && ok;
     {  // all spheres at one point: equal Morton codes all the way down
         std::vector<float> s = random_scene(300);
@@ -174,6 +178,9 @@ int main() {
         for (uint32_t i = 0; i < 400; ++i) s[4 * i + 3] = 0.3f;
         ok = check_tree(s, "deep chain") && ok;
     }
+    all = all && ok;
+    }
+    ok = all;
     for (int kind = 0; kind < 4; ++kind)
         for (auto wh : {std::pair<uint32_t, uint32_t>{1, 1}, {2, 1}, {17, 9}, {256, 128}}) ok = check_sky(wh.first, wh.second, kind) && ok;
     ok = check_host_math() && ok;

@@ -29,7 +29,8 @@ int main(int argc, char** argv) {
     const uint32_t n = (uint32_t)(sph.size() / 4);
     const size_t m = rays.size() / 6;
     pt::Lbvh t;
-    pt::build_lbvh(sph.data(), n, t);
+    const bool sah = argc > 3 && strcmp(argv[3], "sah") == 0;  // split rule of the host build (lbvh.h LbvhSplit)
+    pt::build_lbvh(sph.data(), n, t, sah ? pt::LbvhSplit::Sah : pt::LbvhSplit::Morton);
     std::vector<float4> lin(n);
     for (uint32_t i = 0; i < n; ++i) lin[i] = make_float4(sph[4 * i], sph[4 * i + 1], sph[4 * i + 2], sph[4 * i + 3] * sph[4 * i + 3]);
     pt::LbvhView v;

@@ -105,6 +105,39 @@ def _build(tracer, scene, cam, w, h, build):
     return idx, t, info, binfo, arrays
 
 
+@pytest.mark.parametrize("kind,n", [("random", 3), ("random", 5), ("random", 1000), ("random", 10000), ("duplicates", 5000),
+                                    ("one_point", 257), ("non_finite", 2000), ("grid", 4096)])
+def test_surface_area_build_gives_the_same_hits_and_radiance(pta, tracer, oracle, kind, n):
+    """IR_BUILD_HOST_SAH: another tree over the same spheres (lbvh.h LbvhSplit::Sah); primary (index, t) and the radiance of a
+    few samples per pixel are bit for bit those of the Morton tree — the result never depends on the tree."""
+    from path_tracer_amd import _capi, workloads as W
+    w, h = 96, 54
+    xyzr = SCENES[kind](n, 4321 + n)
+    scene = _scene(xyzr)
+    cam = W.camera_s2(w, h)
+    tracer.set_active_camera(cam)
+    tracer.set_integrator(bounces=6, max_compulsory_bounces=2, seed=W.RNG_SEED)
+    out = {}
+    for build in (_capi.IR_BUILD_HOST, _capi.IR_BUILD_HOST_SAH):
+        idx, t, info, binfo, arrays = _build(tracer, scene, cam, w, h, build)
+        assert binfo["builder"] == build
+        assert np.array_equal(np.sort(arrays[2]), np.arange(n, dtype=np.int32))
+        tracer.set_accel(_capi.IR_ACCEL_LBVH)
+        tracer.set_accel_build(build)
+        try:
+            tracer.render(scene, w, h, False, spp=6)
+            rad = tracer.get_radiance()[0].copy()
+        finally:
+            tracer.set_accel_build(_capi.IR_BUILD_AUTO)
+            tracer.set_accel(_capi.IR_ACCEL_AUTO)
+        out[build] = (idx, t, rad, info)
+    a, b = out[_capi.IR_BUILD_HOST], out[_capi.IR_BUILD_HOST_SAH]
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+    assert a[2].tobytes() == b[2].tobytes()
+    if n >= 1000 and kind == "random":
+        assert a[3] != b[3]  # really another tree
+
+
 @pytest.mark.parametrize("kind,n", [
     ("random", 3), ("random", 4), ("random", 5), ("random", 64), ("random", 1000), ("random", 10000), ("random", 200000), ("random", 2100000),
     ("duplicates", 300), ("duplicates", 5000), ("one_point", 3), ("one_point", 257), ("non_finite", 2000), ("grid", 4096),

@@ -50,8 +50,9 @@ def _rays(xyzr, n_each, rng, cam_rays):
     return np.ascontiguousarray(np.concatenate(out, 0), dtype=np.float32)
 
 
+@pytest.mark.parametrize("split", ["morton", "sah"])
 @pytest.mark.parametrize("n", [1, 3, 5, 64, 1000, 10000])
-def test_lbvh_matches_scan(checker, oracle, tmp_path, n):
+def test_lbvh_matches_scan(checker, oracle, tmp_path, n, split):
     from path_tracer_amd import workloads as W
     scene = W.scene_s2(n=n)
     xyzr, _ = scene.flat_spheres()
@@ -63,12 +64,13 @@ def test_lbvh_matches_scan(checker, oracle, tmp_path, n):
     sp, rp = tmp_path / "s.bin", tmp_path / "r.bin"
     xyzr.tofile(sp)
     r.tofile(rp)
-    res = subprocess.run([checker, str(sp), str(rp)], capture_output=True, text=True)
+    res = subprocess.run([checker, str(sp), str(rp), split], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.startswith("ok")
 
 
-def test_lbvh_duplicates_and_ties(checker, tmp_path):
+@pytest.mark.parametrize("split", ["morton", "sah"])
+def test_lbvh_duplicates_and_ties(checker, tmp_path, split):
     """Coincident spheres: the scan keeps the lowest index (strict '<', integrator.rs:121); so must the LBVH."""
     rng = np.random.default_rng(7)
     base = rng.uniform(-5, 5, (200, 3)).astype(np.float32)
@@ -79,5 +81,31 @@ def test_lbvh_duplicates_and_ties(checker, tmp_path):
     sp, rp = tmp_path / "s.bin", tmp_path / "r.bin"
     np.ascontiguousarray(xyzr, dtype=np.float32).tofile(sp)
     np.ascontiguousarray(np.concatenate([o, d], 1), dtype=np.float32).tofile(rp)
-    res = subprocess.run([checker, str(sp), str(rp)], capture_output=True, text=True)
+    res = subprocess.run([checker, str(sp), str(rp), split], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_sah_tree_on_clustered_and_degenerate_scenes(checker, tmp_path):
+    """The surface-area build (IR_BUILD_HOST_SAH) on what its binning can trip over: tight clusters far apart, all centres
+    on one line, all centres equal, huge and tiny radii side by side: same (t, index) as the scan."""
+    rng = np.random.default_rng(11)
+    scenes = []
+    centres = rng.uniform(-200, 200, (12, 3))
+    scenes.append(np.concatenate([(centres[rng.integers(0, 12, 3000)] + rng.normal(scale=0.5, size=(3000, 3))),
+                                  rng.uniform(0.05, 0.3, (3000, 1))], 1))
+    line = np.zeros((500, 4)); line[:, 0] = np.linspace(-50, 50, 500); line[:, 3] = 0.3
+    scenes.append(line)
+    same = np.zeros((300, 4)); same[:, 2] = -5.0; same[:, 3] = rng.uniform(0.1, 2.0, 300)
+    scenes.append(same)
+    mixed = np.concatenate([rng.uniform(-10, 10, (800, 3)), rng.choice([1e-3, 0.2, 30.0], (800, 1))], 1)
+    scenes.append(mixed)
+    for k, xyzr in enumerate(scenes):
+        xyzr = np.ascontiguousarray(xyzr, dtype=np.float32)
+        n = xyzr.shape[0]
+        o = (xyzr[rng.integers(0, n, 8000), :3] + rng.normal(scale=3.0, size=(8000, 3))).astype(np.float32)
+        d = (xyzr[rng.integers(0, n, 8000), :3] - o + rng.normal(scale=0.1, size=(8000, 3))).astype(np.float32)
+        sp, rp = tmp_path / f"s{k}.bin", tmp_path / f"r{k}.bin"
+        xyzr.tofile(sp)
+        np.ascontiguousarray(np.concatenate([o, d], 1), dtype=np.float32).tofile(rp)
+        res = subprocess.run([checker, str(sp), str(rp), "sah"], capture_output=True, text=True)
+        assert res.returncode == 0, f"scene {k}: " + res.stdout + res.stderr
