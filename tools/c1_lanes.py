@@ -27,7 +27,7 @@ for blk in blocks:
     pr = rt.get_lane_profile()
     top = list(pr.values())[0]
     print("block %3d: paths kernel %.3f ms (sequence %.3f ms); wave iterations %d, lane utilisation %.3f, path samples %d, "
-          "lane iterations per path sample %.2f, us per wave iteration at 6144 resident waves %.2f" %
+          "lane iterations per path sample %.2f, us per wave iteration at 7168 resident waves %.2f" %
           (blk, best, seq, top[0], top[1] / max(1, 64 * top[0]), st["samples"], top[1] / max(1, st["samples"]),
-           best * 1e3 / max(1.0, top[0] / 6144.0)), flush=True)
+           best * 1e3 / max(1.0, top[0] / 7168.0)), flush=True)
     rt.close()
