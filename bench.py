@@ -165,8 +165,8 @@ def main():
     ap.add_argument("--sky-filter", choices=["nearest", "bilinear"], default="nearest",
                     help="nearest = the reference (exr.rs:20-23) and the metric's; bilinear = north_star's variant (ir_set_sky_filter)")
     ap.add_argument("--sample-block", type=int, default=None,
-                    help="ir_set_sample_block; default: IR_SAMPLE_BLOCK_AUTO (0), which is the library default of 128 on C2, C4 and C5 "
-                         "and 64 on C3 (config.sample_block says what the run used)")
+                    help="ir_set_sample_block; default: IR_SAMPLE_BLOCK_AUTO (0): 124 on C2 (8 x 124 + 32), 127 on C4 and C5, 60 on C3 "
+                         "(config.sample_block says what the run used)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a box with ONE GPU: every rank uses device 0 and the exchange step goes "
                          "through gloo on host copies (RCCL refuses two ranks on one device). Not a measurement.")
@@ -409,15 +409,20 @@ def main():
         key = args.workload + ("" if (sky_w, sky_h, args.sky_filter) == (1024, 512, "nearest") else f"_sky{sky_w}x{sky_h}_{args.sky_filter}")
         tpath = os.path.join(ROOT, "profiles", f"r3_pmc_roofline_{key}.json")
         pmc_launch_spp = {"c2": 1024, "c3": 256, "c4": 4096, "c5": 4096}  # samples per pixel of the launch the passes profiled
-        if per_launch == pmc_launch_spp[args.workload] and BOUNCES == 8 and args.sky_sampling == "bsdf" and os.path.exists(tpath):
+        # (a call of many launches cuts them at whole sample blocks: C5's are 4061 samples where the passes profiled 4096;
+        # per-launch quantities are scaled by that ratio, and a launch further than a quarter off gets no counters)
+        scale = per_launch / pmc_launch_spp[args.workload]
+        if 0.8 <= scale <= 1.25 and BOUNCES == 8 and args.sky_sampling == "bsdf" and os.path.exists(tpath):
             with open(tpath) as f:
                 pmc = json.load(f)
             traffic = pmc.get("traffic_bytes_per_launch")
+            if traffic is not None:
+                traffic *= scale
             lane_util = pmc.get("lane_utilisation")
             l2_hit = pmc.get("l2_hit_rate")
             bound = pmc.get("bound", "valu")
             if pmc.get("executed_flop_per_launch"):
-                executed_tf = pmc["executed_flop_per_launch"] / (avg_launch_ms * 1e-3) / 1e12
+                executed_tf = pmc["executed_flop_per_launch"] * scale / (avg_launch_ms * 1e-3) / 1e12
             pmc_source = pmc.get("source")
             limiter = pmc.get("limiter")
         hbm_gbs = algorithmic_bytes / (avg_launch_ms * 1e-3) / 1e9

@@ -175,7 +175,10 @@ int ir_set_integrator(ir_context* ctx, uint32_t bounces, uint32_t max_compulsory
  * IR_SAMPLE_BLOCK_AUTO (0): 128, halved until the launch has at least 26000 x 256 (pixel, block) tasks, not below 8 (4 on
  * frames of fewer than 4096 x 256 pixels): a launch of few long blocks lasts as long as its longest block runs on one lane
  * (the reference's own headless case, 800x450 at 64 spp: 4-sample blocks render it in 0.37 of the time of one 64-sample
- * block per pixel; 1080p at 128 spp: 32-sample blocks, 0.8 of the time).  A pure
+ * block per pixel; 1080p at 128 spp: 32-sample blocks, 0.8 of the time).  A block of 32 samples or more is then replaced by
+ * the size within an eighth of it whose last block, spp mod size, comes closest to a quarter block (sizes dividing spp
+ * skipped, the larger size on a tie; 1080p at 1024 spp: 8 blocks of 124 and one of 32): a launch ends on its last blocks
+ * and drains for the length of a short one.  A pure
  * function of the pixels this rank owns — 4096 per 64x64 tile — and spp; ir_get_sample_block returns what a render of
  * that shape would use, so that a caller (or a checker) can reproduce the order of the sums. */
 int ir_set_sample_block(ir_context* ctx, uint32_t samples_per_block);

@@ -141,10 +141,25 @@ int selected_accel(const ir_context* ctx) {
 // the sum order.
 constexpr uint32_t kAutoMinWorkgroups = 26000;
 constexpr uint32_t kAutoSmallFrameWorkgroups = 4096;
+// Round 3: a launch ends on the tasks of the LAST block of its pixels (pt_kernels.hip decode_task), so a block of 32 samples
+// or more is then replaced by the size within an eighth of it whose last block (spp mod size) comes closest to a quarter
+// block (the larger size on a tie; sizes that divide spp are skipped): 1080p x 1024 spp: 8 x 124 + 32; x 256 spp: 4 x 60 +
+// 16.  The launch then drains for the length of a short task instead of a full one (tools/wave_timeline.py,
+// tools/drain_ab.sh: C2 +1.5 %, C3 +3 %).  Shorter blocks are dealt out over 16 queues, which all end at the same time.
 uint32_t auto_sample_block(uint32_t wgs_per_block, uint32_t spp) {
     const uint32_t min_block = wgs_per_block < kAutoSmallFrameWorkgroups ? 4u : 8u;
     uint32_t sb = 128;
     while (sb > min_block && (uint64_t)wgs_per_block * ((spp + sb - 1) / sb) < kAutoMinWorkgroups) sb /= 2;
+    if (sb >= 32 && spp > sb) {
+        uint32_t best = 0, best_d = 0xffffffffu;
+        for (uint32_t c = sb + sb / 8; c >= sb - sb / 8; --c) {
+            const uint32_t r = spp % c;
+            if (r == 0) continue;
+            const uint32_t d = 4 * r > c ? 4 * r - c : c - 4 * r;
+            if (d < best_d) best_d = d, best = c;
+        }
+        if (best) sb = best;
+    }
     return sb;
 }
 
@@ -388,7 +403,7 @@ void ir_destroy(ir_context* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
-    release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_skyquad); release(ctx->d_rays);
+    release(ctx->d_spheres); release(ctx->d_shade); release(ctx->d_skybox); release(ctx->d_skyquad); release(ctx->d_wave_times); release(ctx->d_rays);
     if (ctx->h_argb) (void)hipHostFree(ctx->h_argb);
     release(ctx->d_sum); release(ctx->d_counts); release(ctx->d_argb); release(ctx->d_hit_idx); release(ctx->d_hit_t);
     release(ctx->d_stats); release(ctx->d_partials);
@@ -849,8 +864,30 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
             a.task_counters_next = pairs + (ctx->launch_parity ^ 1u) * pt::kTaskCounterPairStride;
             ctx->launch_parity ^= 1u;
         }
+        // diagnostics for tools/wave_timeline.py: every wave of the path kernel stamps its start and end; the launch is
+        // waited for and the stamps are written to the named file (one line per wave), launch after launch
+        static const char* const wave_times_path = getenv("IR_DEBUG_WAVE_TIMES");
+        constexpr uint32_t kWaveTimesCap = 1u << 16;
+        a.wave_times = nullptr;
+        a.wave_times_cap = 0;
+        if (wave_times_path) {
+            IR_TRY(ensure(ctx, ctx->d_wave_times, (size_t)kWaveTimesCap * 16));
+            IR_HIP(ctx, hipMemsetAsync(ctx->d_wave_times.p, 0, (size_t)kWaveTimesCap * 16, ctx->stream));
+            a.wave_times = (unsigned long long*)ctx->d_wave_times.p;
+            a.wave_times_cap = kWaveTimesCap;
+        }
         const uint32_t timer = (uint32_t)(ctx->launches_timed % ir_context::kTimerRing);
         const hipError_t le = pt::launch_render(a, accel, ctx->stats_enabled, ctx->stream, ctx->ev_p0[timer], ctx->ev_p1[timer]);
+        if (wave_times_path && le == hipSuccess) {
+            std::vector<unsigned long long> stamps((size_t)kWaveTimesCap * 2);
+            IR_HIP(ctx, hipMemcpyAsync(stamps.data(), ctx->d_wave_times.p, stamps.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            IR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (FILE* f = fopen(wave_times_path, "w")) {
+                for (uint32_t wv = 0; wv < kWaveTimesCap; ++wv)
+                    if (stamps[2 * (size_t)wv]) fprintf(f, "%llu %llu\n", stamps[2 * (size_t)wv], stamps[2 * (size_t)wv + 1]);
+                fclose(f);
+            }
+        }
         if (le != hipSuccess) {
             ctx->task_counters_clean = false;  // whatever ran may have left the counters anywhere
             return fail(ctx, IR_EDEVICE, "%s: launch failed: %s", who, hipGetErrorString(le));

@@ -58,6 +58,7 @@ struct ir_context {
     int sky_sampling = IR_SKY_SAMPLING_BSDF;
     irx::DeviceBuf d_sky_marginal, d_sky_cond, d_sky_pdf, d_sky_marginal_guide, d_sky_cond_guide;
     bool sky_tables_valid = false;
+    irx::DeviceBuf d_wave_times;   // diagnostics (IR_DEBUG_WAVE_TIMES): start / end time of the path kernel's waves
     irx::DeviceBuf d_skyquad;      // footprint table of the bilinear lookup (pt_kernels.h skyquad), built for large skies
     bool sky_quad_valid = false;
     int accel = IR_ACCEL_AUTO;

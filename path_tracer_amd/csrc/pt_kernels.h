@@ -73,6 +73,10 @@ struct RenderArgs {
     LbvhView bvh;  // used by the LBVH instantiation only
 
     unsigned long long* stats;  // kNumStats counters or nullptr (only read by the STATS instantiation)
+    // Diagnostics (tools/wave_timeline.py, IR_DEBUG_WAVE_TIMES): when not nullptr, every wave of the path kernel stores the
+    // 100 MHz realtime counter at its start and at its end, [2 * wave] and [2 * wave + 1], for waves below wave_times_cap.
+    unsigned long long* wave_times;
+    uint32_t wave_times_cap;
 };
 
 struct HitsArgs {

@@ -261,9 +261,17 @@ __global__ __launch_bounds__(WG) void primary_kernel(const RenderArgs a) {
     }
 }
 
+// Diagnostics: the wave's start or end time (RenderArgs::wave_times), two scalar instructions and a store when enabled
+__device__ __forceinline__ void stamp_wave(const RenderArgs& a, uint32_t which) {
+    if (a.wave_times) {
+        const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wave < a.wave_times_cap && (threadIdx.x & 63u) == 0u) a.wave_times[2 * (size_t)wave + which] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // State of the task a lane works on: a few registers; what follows from (pixel, block) is recomputed where it is needed.
 struct TaskState {
-    uint32_t pixel, task, s;  // task id = list entry x n_blocks + block; s = samples of the block done so far
+    uint32_t pixel, task, s;  // task = list entry x n_blocks + block (the block sum's slot); s = samples of the block done so far
     float4 acc;               // the block sum
 };
 struct PrimaryHit {  // a path pixel's record from primary_kernel
@@ -274,6 +282,21 @@ struct PrimaryHit {  // a path pixel's record from primary_kernel
 __device__ __forceinline__ uint32_t task_spp(const RenderArgs& a, uint32_t blk) {
     const uint32_t first = blk * a.sample_block;
     return (a.spp - first < a.sample_block) ? a.spp - first : a.sample_block;
+}
+// Task id -> (list entry, block).  The ids of the FULL blocks come first, pixel by pixel (a pixel's blocks are neighbours:
+// the lanes of a wave then share primary hits, which the tree kernel's loads like); the ids of the short last blocks
+// (spp % sample_block samples, one per pixel) come after all of them.  With one queue, a launch therefore ends on short
+// tasks and drains for the length of a short task instead of a full one (tools/wave_timeline.py: the last wave of a C3
+// launch of four 64-sample blocks per pixel ended 3 ms after the median wave, 9 % of the launch).
+__device__ __forceinline__ void decode_task(const RenderArgs& a, uint32_t n_entries, uint32_t task, uint32_t& entry, uint32_t& blk) {
+    const uint32_t n_full = a.spp / a.sample_block, full_tasks = n_entries * n_full;
+    if (task < full_tasks) {
+        entry = task / n_full;
+        blk = task - entry * n_full;
+    } else {
+        entry = task - full_tasks;
+        blk = n_full;
+    }
 }
 __device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t entry) {
     const float4 r0 = a.prim[2 * (size_t)entry], r1 = a.prim[2 * (size_t)entry + 1];
@@ -314,12 +337,14 @@ __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t
 // grid = 16 x owned tiles workgroups of 256; a lane traces its pixel's primary ray, finishes a sky pixel on the spot
 // (finish_sky_pixel) and otherwise runs the pixel's block as its only task, through the same loop body.
 template <bool STATS, bool SKYMIS, int WG = 256, bool DIRECT = false>
-__global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(WG, (WG == 256 && !SKYMIS && !STATS) ? 7 : 1) void paths_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     __shared__ uint32_t s_exhausted;  // bit q: a wave of this workgroup found task queue q exhausted
+    stamp_wave(a, 0);
     if (threadIdx.x == 0) s_exhausted = 0u;
     stage_spheres(s_sph, a.spheres, a.n_spheres);  // (ends with the barrier that publishes s_exhausted too)
-    const uint32_t n_tasks = DIRECT ? 0u : a.task_counters[0] * a.n_blocks;  // path pixels (primary_kernel) x sample blocks
+    const uint32_t n_entries = DIRECT ? 0u : a.task_counters[0];  // path pixels (primary_kernel)
+    const uint32_t n_tasks = n_entries * a.n_blocks;              // x sample blocks
     TaskPool pool;
     if constexpr (!DIRECT) pool = task_pool_begin(n_tasks, a.n_queues);
 
@@ -407,9 +432,9 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
         // copies per iteration)
         finished = finished || took == kTaskExhausted;
         if (took == kTaskGot) {
-            const uint32_t entry = task / a.n_blocks;  // task = list entry x n_blocks + block
-            const uint32_t blk = task - entry * a.n_blocks;
-            t.task = task;
+            uint32_t entry, blk;
+            decode_task(a, n_entries, task, entry, blk);
+            t.task = entry * a.n_blocks + blk;  // where the block sum goes: a pixel's blocks side by side (merge_kernel)
             p0 = load_primary(a, entry);
             if (STATS) p0_disc = a.prim_disc[entry];
             t.pixel = p0.pixel;
@@ -525,6 +550,7 @@ __global__ __launch_bounds__(WG) void paths_kernel(const RenderArgs a) {
         }
     }
 
+    stamp_wave(a, 1);
     if (STATS) {
         // algorithmic counts, as the reference would execute them (primary ray per sample)
         atomicAdd(&a.stats[0], (unsigned long long)n_samples);
@@ -562,9 +588,11 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
     __shared__ uint32_t s_exhausted;  // bit q: a wave of this workgroup found task queue q exhausted
+    stamp_wave(a, 0);
     if (threadIdx.x == 0) s_exhausted = 0u;
     __syncthreads();
-    const uint32_t n_tasks = a.task_counters[0] * a.n_blocks;
+    const uint32_t n_entries = a.task_counters[0];
+    const uint32_t n_tasks = n_entries * a.n_blocks;
     TaskPool pool = task_pool_begin(n_tasks, a.n_queues);
     uint32_t n_samples = 0, n_traces = 0, n_disc = 0, n_hits = 0;
     WorkCounters wc = {0, 0, 0};
@@ -634,9 +662,10 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
             const int took = take_task(pool, a.task_counters, &s_exhausted, a.n_queues, n_tasks, want, task);
             finished = finished || took == kTaskExhausted;
             if (took == kTaskGot) {
-                const uint32_t entry = task / a.n_blocks;
+                uint32_t entry, blk;
+                decode_task(a, n_entries, task, entry, blk);
                 task_word(0) = entry;
-                task_word(1) = task - entry * a.n_blocks;
+                task_word(1) = blk;
                 task_word(2) = 0u;
                 task_word(3) = task_word(4) = task_word(5) = task_word(6) = 0u;  // the block sum starts at +0
                 have = true;
@@ -778,6 +807,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
     }
     if (STATS) n_disc += wc.disc;
 
+    stamp_wave(a, 1);
     if (STATS) {
         atomicAdd(&a.stats[0], (unsigned long long)n_samples);
         atomicAdd(&a.stats[1], (unsigned long long)n_traces);
@@ -973,7 +1003,8 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     // frame is a task per pixel: 4K at 1 spp took 1.0 ms behind one cursor) or few tasks per wave
     // (C1: every wave asks in the first microseconds, then every few iterations) need the requests spread out.
     const uint32_t task_samples = a.spp < a.sample_block ? a.spp : a.sample_block;  // (the last block may be shorter still)
-    a.n_queues = (task_samples >= 64 && max_tasks >= (2ull << 20)) ? 1u : kTaskQueues;
+    // (One queue is also what lets a launch end on its short last blocks, decode_task.)
+    a.n_queues = (task_samples >= 24 && max_tasks >= (2ull << 20)) ? 1u : kTaskQueues;
     static const int forced_queues = getenv("IR_DEBUG_TASK_QUEUES") ? atoi(getenv("IR_DEBUG_TASK_QUEUES")) : 0;  // tools/ only
     if (forced_queues >= 1 && forced_queues <= (int)kTaskQueues && (forced_queues & (forced_queues - 1)) == 0) a.n_queues = (uint32_t)forced_queues;
     const void* paths = nullptr;

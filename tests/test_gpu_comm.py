@@ -123,7 +123,9 @@ def test_auto_sample_block_and_memory_bounded_blocks(tracer, oracle):
     lib, ctx = _capi.lib, tracer._ctx
     scene = W.scene_s1()
     # C1's shape: 800x450 = 13x8 tiles = 1664 workgroups-worth of pixels (a small frame: blocks down to 4); 64 spp -> blocks of 4
-    # (16 x 1664 >= 26000); 1080p = 8160: 64 / 128 spp -> 16 / 32, and a launch of few samples ends in one block per pixel
+    # (16 x 1664 >= 26000); 1080p = 8160: 64 spp -> 16; from 32-sample blocks on, the size within an eighth whose last block
+    # comes closest to a quarter block (128 spp: 32 -> 4 x 30 + 8; 256: 64 -> 4 x 60 + 16; 1024: 128 -> 8 x 124 + 32); a launch
+    # of few samples ends in one block per pixel
     w, h, spp = 800, 450, 64
     cam = W.default_camera(w, h)
     tracer.set_active_camera(cam)
@@ -131,7 +133,7 @@ def test_auto_sample_block_and_memory_bounded_blocks(tracer, oracle):
     sb = C.c_uint32()
     _capi.check(ctx, lib.ir_get_sample_block(ctx, w, h, spp, C.byref(sb)))
     assert sb.value == 4
-    for (w_, h_, spp_, want_sb) in ((1920, 1080, 1024, 128), (1920, 1080, 256, 64), (1920, 1080, 128, 32), (1920, 1080, 64, 16),
+    for (w_, h_, spp_, want_sb) in ((1920, 1080, 1024, 124), (1920, 1080, 256, 60), (1920, 1080, 128, 30), (1920, 1080, 64, 16), (1920, 1080, 1000, 138), (1920, 1080, 65536, 131), (1920, 1080, 200, 62),
                                     (1920, 1080, 8, 8), (3840, 2160, 64, 128), (800, 450, 256, 16), (800, 450, 128, 8), (64, 64, 1, 4)):
         _capi.check(ctx, lib.ir_get_sample_block(ctx, w_, h_, spp_, C.byref(sb)))
         assert sb.value == want_sb, (w_, h_, spp_, sb.value)

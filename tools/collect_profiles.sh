@@ -29,6 +29,7 @@ PY
 [ -f $o/c1_rate.txt ] && {
   for t in c1_full c1_rate c1_floor c1_sweep c1_lanes lanes_c2 lanes_c3 interactive_latency; do cp $o/$t.txt $p/${r}_$t.txt; done
   cp $o/ta_c3.txt $p/${r}_c3_ta_td_busy_256spp.txt
+  [ -f $o/wave_timeline.txt ] && grep -v amdgpu.ids $o/wave_timeline.txt > $p/${r}_wave_timeline.txt
 }
 [ -f $o/wavefront_mis.txt ] && grep -v amdgpu.ids $o/wavefront_mis.txt > $p/${r}_wavefront_mis.txt
 true

@@ -30,5 +30,9 @@ else
   timeout -k 10 200 python -u tools/lane_profile.py 256 c3 > $out/lanes_c3.txt 2>&1 || exit 1
   timeout -k 10 300 python -u tools/interactive_latency.py > $out/interactive_latency.txt 2>&1 || exit 1
   bash tools/pmc_ta.sh $tag/ta_c3 c3 256 > $out/ta_c3.txt 2>&1 || { tail -5 $out/ta_c3.txt; exit 1; }
+  # when the path kernel's waves end: uniform blocks (128 / 64) against the AUTO size, whose last block is a quarter block
+  for cfg in "c1 64 0" "c2 1024 128" "c2 1024 0" "c3 256 64" "c3 256 0"; do
+    timeout -k 10 120 python -u tools/wave_timeline.py $cfg >> $out/wave_timeline.txt 2>&1 || { tail -5 $out/wave_timeline.txt; exit 1; }
+  done
   tail -3 $out/c1_rate.txt; tail -12 $out/ta_c3.txt
 fi

@@ -12,7 +12,7 @@ one() {  # key cfg spp block kernel bound limiter
   cp $out/r3_pmc_roofline_$1.json profiles/r3_pmc_roofline_$1.json
   echo "== $1"; grep -E "FETCH_SIZE|WRITE_SIZE|lane utilisation|kernel ms" $out/r3_pmc_summary_$1.txt
 }
-one c2 c2 1024 128 paths_kernel valu "VALU issue: the launch's instruction mix priced with the per-opcode issue costs measured on this chip (tools/ubench_valu.hip) accounts for the kernel's cycles; 2.6 cycles per VALU wave-instruction and SIMD, 0.68 of the lanes active" &&
+one c2 c2 1024 0 paths_kernel valu "VALU issue: the launch's instruction mix priced with the per-opcode issue costs measured on this chip (tools/ubench_valu.hip) accounts for the kernel's cycles; 2.6 cycles per VALU wave-instruction and SIMD, 0.68 of the lanes active" &&
 one c3 c3 256 0 paths_lbvh valu "L1 data path (TD busy 0.85 of the kernel's cycles, tools/pmc_ta.sh) with VALU issue close behind; the object prices the launch against the FP32 vector peak" &&
-one c4 c4 4096 128 paths_kernel valu "VALU issue, as C2 (same kernel and scene at 3840x2160)" &&
-one c5 c5 4096 128 paths_kernel valu "VALU issue; every sample ends in a sky lookup (1024x512 sky: 8 MB, L2/Infinity-Cache resident)"
+one c4 c4 4096 0 paths_kernel valu "VALU issue, as C2 (same kernel and scene at 3840x2160)" &&
+one c5 c5 4096 0 paths_kernel valu "VALU issue; every sample ends in a sky lookup (1024x512 sky: 8 MB, L2/Infinity-Cache resident)"
