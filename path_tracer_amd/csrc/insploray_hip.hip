@@ -812,7 +812,8 @@ int render_impl(ir_context* ctx, uint32_t width, uint32_t height, uint32_t spp, 
     const double unit = (double)n * (double)(accel == pt::kAccelLbvh ? 64 : (ctx->n_spheres < 8 ? 8 : ctx->n_spheres));
     uint32_t chunk = (uint32_t)std::fmin(4096.0, std::fmax(1.0, 4.0e12 / unit));
     // whole sample blocks per launch, so that the block structure does not depend on the chunking
-    chunk = chunk < sb ? sb : chunk / sb * sb;
+    // (rounded UP: a 4096-sample call in blocks of 127 is one launch of 32 blocks and the short last one, not two launches)
+    chunk = (chunk + sb - 1) / sb * sb;
     // ... and bound the block sums of one launch (16 B per pixel and block): more launches rather than more memory.  A
     // small sample_block is what a caller sets to get the reference's per-sample sum order; it must not cost 100 GB.
     // The launch also needs the primary-pass records and the task list (36 B per pixel + counters).
