@@ -39,12 +39,13 @@ def c2(pta, tracer):
     return scene, cam, s.copy(), c.copy()
 
 
-def _contract_sum(samples):
+def _contract_sum(samples, block=None):
     """(spp, 3) per-sample radiance -> float32 (r, g, b, weight) summed as ir_render defines it."""
+    block = block or BLOCK
     total = np.zeros(4, dtype=np.float32)
-    for s0 in range(0, samples.shape[0], BLOCK):
+    for s0 in range(0, samples.shape[0], block):
         blk = np.zeros(4, dtype=np.float32)
-        for v in samples[s0:s0 + BLOCK]:
+        for v in samples[s0:s0 + block]:
             blk[0] += v[0]; blk[1] += v[1]; blk[2] += v[2]; blk[3] += np.float32(1.0)
         total += blk
     return total
@@ -172,6 +173,36 @@ def test_c3_full_size_hits_and_sampled_pixels(pta, tracer, oracle):
     assert (c == 256).all() and (s[..., 3] == np.float32(256.0)).all()
     for (x, y) in [(960, 540), (200, 900), (1700, 650), (1000, 420), (50, 1000), (1333, 777)]:
         want = _contract_sum(oracle.pixel_samples(ocam, scene, x, y, 256, bounces=8, rr_start=2, seed=SEED, math_mode=1))
+        assert s[y, x].tobytes() == want.tobytes(), f"pixel ({x},{y}): {s[y, x]} vs {want}"
+
+
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_auto_block_with_a_short_last_block_at_full_size(pta, tracer, oracle, workload):
+    """IR_SAMPLE_BLOCK_AUTO on the bench launches: blocks that do not divide the sample count (C2: 8 x 124 + 32, C3: 4 x 60 +
+    16), the short last blocks dealt out after all the full ones from a single queue (pt_kernels.hip decode_task).  Every
+    pixel got each of its samples once (the weight channel counts them), sampled pixels equal the oracle's per-sample
+    values summed in that block structure."""
+    from path_tracer_amd import _capi, workloads as W
+    if workload == "c2":
+        scene, cam, spp, want_block = W.scene_s1(), W.default_camera(W_, H_), 1024, 124
+        pixels = [(960, 800), (1100, 560), (300, 1000), (1500, 700), (40, 1079), (1919, 600), (960, 300), (700, 650)]
+    else:
+        scene, cam, spp, want_block = W.scene_s2(), W.camera_s2(W_, H_), 256, 60
+        pixels = [(960, 540), (200, 900), (1700, 650), (1333, 777)]
+    tracer.set_active_camera(cam)
+    tracer.set_integrator(bounces=8, max_compulsory_bounces=2, seed=SEED)
+    tracer.set_sample_block(_capi.IR_SAMPLE_BLOCK_AUTO)
+    try:
+        block = tracer.get_sample_block(W_, H_, spp)
+        assert block == want_block and spp % block != 0
+        tracer.render(scene, W_, H_, False, spp=spp)
+        s, c = tracer.get_radiance()
+    finally:
+        tracer.set_sample_block(BLOCK)
+    assert (c == spp).all() and (s[..., 3] == np.float32(spp)).all()
+    ocam = oracle.camera_from(cam, W_, H_)
+    for (x, y) in pixels:
+        want = _contract_sum(oracle.pixel_samples(ocam, scene, x, y, spp, bounces=8, rr_start=2, seed=SEED, math_mode=1), block)
         assert s[y, x].tobytes() == want.tobytes(), f"pixel ({x},{y}): {s[y, x]} vs {want}"
 
 
