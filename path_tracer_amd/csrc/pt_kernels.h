@@ -62,6 +62,7 @@ struct RenderArgs {
     // one set of counters: word 0 = list length; word (1 + q) * kTaskCounterStride = cursor of task queue q
     // (task = list entry * n_blocks + block; queue q holds the ids [q, q + 1) * task_queue_span(n_tasks, n_queues))
     uint32_t* task_counters;
+    uint32_t list_from_end;  // 1: tasks walk the list of path pixels from its end (pt_kernels.hip decode_task; launch_render sets it)
     uint32_t n_queues;  // queues in use, a power of two <= kTaskQueues (launch_render: one when tasks are long and many)
     // The other set of counters, zeroed by this launch's primary pass for the next launch (the context alternates between
     // two sets, which saves a fill per launch), or nullptr when the caller zeroes task_counters itself.

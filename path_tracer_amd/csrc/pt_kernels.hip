@@ -288,6 +288,12 @@ __device__ __forceinline__ uint32_t task_spp(const RenderArgs& a, uint32_t blk) 
 // (spp % sample_block samples, one per pixel) come after all of them.  With one queue, a launch therefore ends on short
 // tasks and drains for the length of a short task instead of a full one (tools/wave_timeline.py: the last wave of a C3
 // launch of four 64-sample blocks per pixel ended 3 ms after the median wave, 9 % of the launch).
+// list_from_end: the list of path pixels is dealt out from its END.  The primary pass lists the frame from its top rows
+// down, and on both benchmark scenes (a camera above its subject: far field at the top of the frame, near field and contact
+// regions at the bottom) the cost of a pixel's samples grows down the list; dealt out from the start, the expensive pixels'
+// blocks are the last full blocks and the launch waits for them (C3: last wave 2.9 ms after the median; from the end: 1.1 ms;
+// C2 +2.3 %, C3 +3.5 % same-box).  Dealing from both ends towards the middle, or round-robin over 16 / 64 bands of the
+// list, gained nothing or lost (profiles/r3_same_box_ab.txt).  A heuristic: the general answer is an order by measured cost.
 __device__ __forceinline__ void decode_task(const RenderArgs& a, uint32_t n_entries, uint32_t task, uint32_t& entry, uint32_t& blk) {
     const uint32_t n_full = a.spp / a.sample_block, full_tasks = n_entries * n_full;
     if (task < full_tasks) {
@@ -297,6 +303,7 @@ __device__ __forceinline__ void decode_task(const RenderArgs& a, uint32_t n_entr
         entry = task - full_tasks;
         blk = n_full;
     }
+    if (a.list_from_end) entry = n_entries - 1u - entry;
 }
 __device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t entry) {
     const float4 r0 = a.prim[2 * (size_t)entry], r1 = a.prim[2 * (size_t)entry + 1];
@@ -1005,6 +1012,8 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
     const uint32_t task_samples = a.spp < a.sample_block ? a.spp : a.sample_block;  // (the last block may be shorter still)
     // (One queue is also what lets a launch end on its short last blocks, decode_task.)
     a.n_queues = (task_samples >= 24 && max_tasks >= (2ull << 20)) ? 1u : kTaskQueues;
+    static const int forced_order = getenv("IR_DEBUG_TASK_ORDER") ? atoi(getenv("IR_DEBUG_TASK_ORDER")) : -1;  // tools/ only: 0 = from the start
+    a.list_from_end = forced_order >= 0 ? (forced_order != 0) : 1u;
     static const int forced_queues = getenv("IR_DEBUG_TASK_QUEUES") ? atoi(getenv("IR_DEBUG_TASK_QUEUES")) : 0;  // tools/ only
     if (forced_queues >= 1 && forced_queues <= (int)kTaskQueues && (forced_queues & (forced_queues - 1)) == 0) a.n_queues = (uint32_t)forced_queues;
     const void* paths = nullptr;
