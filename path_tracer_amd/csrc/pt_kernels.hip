@@ -288,11 +288,12 @@ __device__ __forceinline__ uint32_t task_spp(const RenderArgs& a, uint32_t blk) 
 // (spp % sample_block samples, one per pixel) come after all of them.  With one queue, a launch therefore ends on short
 // tasks and drains for the length of a short task instead of a full one (tools/wave_timeline.py: the last wave of a C3
 // launch of four 64-sample blocks per pixel ended 3 ms after the median wave, 9 % of the launch).
-// list_from_end: the list of path pixels is dealt out from its END.  The primary pass lists the frame from its top rows
-// down, and on both benchmark scenes (a camera above its subject: far field at the top of the frame, near field and contact
-// regions at the bottom) the cost of a pixel's samples grows down the list; dealt out from the start, the expensive pixels'
-// blocks are the last full blocks and the launch waits for them (C3: last wave 2.9 ms after the median; from the end: 1.1 ms;
-// C2 +2.3 %, C3 +3.5 % same-box).  Dealing from both ends towards the middle, or round-robin over 16 / 64 bands of the
+// list_from_end: the list of path pixels is dealt out from its END.  The primary pass lists the frame from image row 0 on,
+// which with the reference's camera above a ground plane is the near field; the rows that border the sky hold the far field,
+// where a pixel sees many spheres and its paths bounce more (tools/cost_map.py, profiles/r3_cost_map.txt: C3 11 box tests per
+// path sample in the first tile row, 40 .. 45 in the last six; C2 1.12 bounce rays per sample in the first, 1.3 .. 1.6 in the
+// last).  Dealt out from the start, the expensive pixels' blocks are the last full blocks and the launch waits for them (C3:
+// last wave 2.9 ms after the median; from the end: 1.1 ms; C2 +2.3 %, C3 +3.5 % same-box).  Dealing from both ends towards the middle, or round-robin over 16 / 64 bands of the
 // list, gained nothing or lost (profiles/r3_same_box_ab.txt).  A heuristic: the general answer is an order by measured cost.
 __device__ __forceinline__ void decode_task(const RenderArgs& a, uint32_t n_entries, uint32_t task, uint32_t& entry, uint32_t& blk) {
     const uint32_t n_full = a.spp / a.sample_block, full_tasks = n_entries * n_full;
