@@ -364,6 +364,25 @@ PT_DEV HitRec trace_linear(const float4* __restrict__ s_sph, uint32_t n, f3 o, f
 //     (|d_k| + e_k + pad) |i_k| <= 1.003 L |i_k|, i.e. < 2.4e-7 L |i_k| against the margin of 1.6e-4 L |i_k|.
 // (Until round 2 the pad was 2^-7 of the L1 distance: 10 % more node visits and 17 % more leaf tests on the 10k scene.)
 // ----------------------------------------------------------------------------------------------------
+// Record `index` of a table of fewer than 2^28 16-byte records (the host checks the sizes at upload): a 32-bit byte offset
+// off the table's uniform base, i.e. one shift and a load with a scalar base where `base[index]` with a 64-bit index costs
+// three or four vector instructions of address arithmetic.
+PT_DEV float4 load16(const float4* __restrict__ base, uint32_t index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (uint32_t)(index << 4));
+#else
+    return base[index];
+#endif
+}
+// y * w + x for y, w < 2^24 (one full-rate v_mad_u32_u24)
+PT_DEV uint32_t row_major(uint32_t y, uint32_t w, uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (y & 0xffffffu) * (w & 0xffffffu) + x;  // the masks tell the compiler both factors fit 24 bits
+#else
+    return y * w + x;
+#endif
+}
+
 struct LbvhView {
     const float4* __restrict__ wide;          // 3 x float4 per record (lbvh.h WideNode): n_inner wide nodes, then climb records
     const float4* __restrict__ leaf_spheres;  // leaf order: (cx, cy, cz, r*r)
@@ -475,8 +494,8 @@ PT_DEV int cursor_pop(LbvhCursor& c, const int* stack, uint32_t stride) {
 // farther; with none hit, pops.  Afterwards c.cur is a record, a leaf (< 0) or kCursorDone.
 template <bool STATS>
 PT_DEV void cursor_inner_step(const LbvhView& v, LbvhCursor& c, int* stack, uint32_t stride, uint32_t& node_visits) {
-    const size_t at = 3 * (size_t)c.cur;  // 48-byte records (lbvh.h)
-    const float4 n0 = v.wide[at], n1 = v.wide[at + 1], n2 = v.wide[at + 2];
+    const uint32_t at = 3u * (uint32_t)c.cur;  // 48-byte records (lbvh.h); fewer than 3 * 2^24 of them: load16's range
+    const float4 n0 = load16(v.wide, at), n1 = load16(v.wide, at + 1u), n2 = load16(v.wide, at + 2u);
     if (STATS) node_visits += 2;  // two box tests
     float tl, tr;
     const bool hl = padded_box_hit(c, mk3(n0.x, n0.y, n0.z), mk3(half_lo(n2.x), half_hi(n2.x), half_lo(n2.y)), tl);
@@ -508,7 +527,7 @@ PT_DEV void cursor_leaf_step(const LbvhView& v, LbvhCursor& c, const int* stack,
     const uint32_t first = leaf >> 3, count = leaf & 7u;
     const f3 o = c.o, d = c.d;
     for (uint32_t k = 0; k < count; ++k) {
-        const float4 s = v.leaf_spheres[first + k];
+        const float4 s = load16(v.leaf_spheres, first + k);
         if (STATS) leaf_tests++;
         f3 oc = o - mk3(s.x, s.y, s.z);
         float b = 2.0f * dot(d, oc);
@@ -573,25 +592,6 @@ PT_DEV f3 sample_hemisphere(f3 n, float r1, float r2) {
     f3 tangent = normalize(cross(up, n));
     f3 bitangent = cross(n, tangent);
     return local.x * tangent + local.y * bitangent + local.z * n;
-}
-
-// Record `index` of a table of fewer than 2^28 16-byte records (the host checks the sizes at upload): a 32-bit byte offset
-// off the table's uniform base, i.e. one shift and a load with a scalar base where `base[index]` with a 64-bit index costs
-// three or four vector instructions of address arithmetic.
-PT_DEV float4 load16(const float4* __restrict__ base, uint32_t index) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (uint32_t)(index << 4));
-#else
-    return base[index];
-#endif
-}
-// y * w + x for y, w < 2^24 (one full-rate v_mad_u32_u24)
-PT_DEV uint32_t row_major(uint32_t y, uint32_t w, uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (y & 0xffffffu) * (w & 0xffffffu) + x;  // the masks tell the compiler both factors fit 24 bits
-#else
-    return y * w + x;
-#endif
 }
 
 // ExrImage::sample, exr.rs:13-24 (nearest texel).  Texels are stored padded to float4.
