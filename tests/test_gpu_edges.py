@@ -141,6 +141,13 @@ def test_limits_are_errors_not_crashes(pta, tracer):
         tracer.set_schedule(7)
     with pytest.raises(pta.InsplorayError):
         tracer.set_sky_filter(5)
+    with pytest.raises(pta.InsplorayError):
+        tracer.set_accel_build(9)
+    # a sky beyond what the kernels' 32-bit texel offsets reach (2^28 texels, 2^24 per side) is refused before it is read
+    import ctypes as C
+    tiny = (C.c_float * 3)(1.0, 1.0, 1.0)
+    for (sw, sh) in ((1 << 24, 1), (1, 1 << 24), (1 << 14, 1 << 14)):
+        assert _capi.lib.ir_set_skybox(tracer._ctx, tiny, sw, sh) == _capi.IR_ELIMIT
     # the context is still usable afterwards
     tracer.set_active_camera(W.default_camera(32, 18))
     tracer.render(scene, 32, 18, False, spp=2)
