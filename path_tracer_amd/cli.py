@@ -82,6 +82,9 @@ def main(argv=None):
     ap.add_argument("--sky-sampling", choices=["bsdf", "mis"], default="bsdf",
                     help="bsdf: the reference's estimator; mis: sky importance sampling (extension)")
     ap.add_argument("--accel", choices=["auto", "linear", "lbvh"], default="auto")
+    ap.add_argument("--accel-build", choices=["auto", "host", "device", "sah"], default="auto",
+                    help="LBVH builder (ir_set_accel_build); sah: surface-area splits on the host, a slower build and a faster "
+                         "tree for a scene rendered with many samples")
     ap.add_argument("--sample-block", default="128",
                     help="samples per accumulation block (ir_set_sample_block): a number, or 'auto' = sized for throughput "
                          "(the order of the sums follows it; 128 is the library default)")
@@ -100,6 +103,8 @@ def main(argv=None):
         rt.set_sky_filter(_capi.IR_SKY_BILINEAR if args.sky_filter == "bilinear" else _capi.IR_SKY_NEAREST)
         rt.set_sky_sampling(_capi.IR_SKY_SAMPLING_MIS if args.sky_sampling == "mis" else _capi.IR_SKY_SAMPLING_BSDF)
         rt.set_accel({"auto": _capi.IR_ACCEL_AUTO, "linear": _capi.IR_ACCEL_LINEAR, "lbvh": _capi.IR_ACCEL_LBVH}[args.accel])
+        rt.set_accel_build({"auto": _capi.IR_BUILD_AUTO, "host": _capi.IR_BUILD_HOST, "device": _capi.IR_BUILD_DEVICE,
+                            "sah": _capi.IR_BUILD_HOST_SAH}[args.accel_build])
         rt.set_sample_block(_capi.IR_SAMPLE_BLOCK_AUTO if args.sample_block == "auto" else int(args.sample_block))
         resumed = 0
         if args.resume:

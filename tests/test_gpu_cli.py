@@ -59,3 +59,16 @@ def test_cli_checkpoint_resume_bit_identical(tmp_path, capsys):
     assert (img.width, img.height) == (96, 54) and np.allclose(img.pixels_buffer.reshape(54, 96, 3), mean[::-1], rtol=1e-6)
     ppm = (tmp_path / "f.ppm").read_bytes()
     assert ppm.startswith(b"P6\n96 54\n255\n") and len(ppm) == len(b"P6\n96 54\n255\n") + 96 * 54 * 3
+
+
+def test_cli_surface_area_build_same_bits(tmp_path, capsys):
+    """--accel-build sah: another tree over the same 10 000 spheres, the same accumulator bit for bit."""
+    from path_tracer_amd import cli
+    common = ["--scene", "s2", "--width", "64", "--height", "36", "--bounces", "6", "--spp", "4", "--accel", "lbvh"]
+    assert cli.main(common + ["--checkpoint", str(tmp_path / "auto.npz")]) == 0
+    assert cli.main(common + ["--accel-build", "sah", "--checkpoint", str(tmp_path / "sah.npz")]) == 0
+    lines = [json.loads(x) for x in capsys.readouterr().out.strip().splitlines()]
+    assert lines[0]["accel"]["nodes"] > 1000 and lines[1]["accel"]["nodes"] > 1000
+    assert lines[0]["accel"]["nodes"] != lines[1]["accel"]["nodes"]  # really another tree
+    a, b = np.load(tmp_path / "auto.npz"), np.load(tmp_path / "sah.npz")
+    assert a["sums"].tobytes() == b["sums"].tobytes() and a["counts"].tobytes() == b["counts"].tobytes()
