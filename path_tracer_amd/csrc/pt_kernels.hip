@@ -344,8 +344,13 @@ __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t
 // 1 spp 70 us instead of 160).  The DIRECT instantiation is a lane per pixel: no primary pass, no list, no counters;
 // grid = 16 x owned tiles workgroups of 256; a lane traces its pixel's primary ray, finishes a sky pixel on the spot
 // (finish_sky_pixel) and otherwise runs the pixel's block as its only task, through the same loop body.
-template <bool STATS, bool SKYMIS, int WG = 256, bool DIRECT = false>
-__global__ __launch_bounds__(WG, (WG == 256 && !SKYMIS && !STATS) ? 7 : 1) void paths_kernel(const RenderArgs a) {
+// RELAXED: the instantiation without the 7-waves-per-SIMD register budget.  The budget (69 VGPRs instead of 73: +1.3 % on
+// C2, +2 % on C5) is paid with scalar registers kept in vector lanes, and the bilinear sky lookup is where they are read
+// back: under the bilinear filter the launch runs 2.4 % faster without the budget on the cache-resident sky and 8 % faster
+// on one in HBM, which is bound by L2 misses, not by issue (C5 under an 8192x4096 sky: 109 vs 118 Gsamples/s; same-box
+// runs, profiles/r3_same_box_ab.txt).  launch_render picks this one for bilinear launches.
+template <bool STATS, bool SKYMIS, int WG = 256, bool DIRECT = false, bool RELAXED = false>
+__global__ __launch_bounds__(WG, (WG == 256 && !SKYMIS && !STATS && !RELAXED) ? 7 : 1) void paths_kernel(const RenderArgs a) {
     extern __shared__ float4 s_sph[];
     __shared__ uint32_t s_exhausted;  // bit q: a wave of this workgroup found task queue q exhausted
     stamp_wave(a, 0);
@@ -941,6 +946,7 @@ hipError_t init_kernels() {
     const void* big_lds[] = {(const void*)paths_kernel<false, false>,          (const void*)paths_kernel<true, false>,
                              (const void*)paths_kernel<false, true>,           (const void*)paths_kernel<true, true>,
                              (const void*)paths_kernel<false, false, 1024>,    (const void*)paths_kernel<true, false, 1024>,
+                             (const void*)paths_kernel<false, false, 256, false, true>,
                              (const void*)paths_kernel<false, false, 256, true>, (const void*)paths_kernel<true, false, 256, true>,
                              (const void*)paths_kernel<false, true, 256, true>,  (const void*)paths_kernel<true, true, 256, true>,
                              (const void*)primary_kernel<kAccelLinear, false, 1024>, (const void*)primary_kernel<kAccelLinear, true, 1024>,
@@ -1038,6 +1044,7 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         else hipLaunchKernelGGL((primary_kernel<kAccelLinear, false, 1024>), dim3(a.wgs_per_layer / 4), dim3(1024), lds, stream, a);
         paths = stats ? (skymis ? (const void*)paths_kernel<true, true> : (const void*)paths_kernel<true, false>)
                       : (skymis ? (const void*)paths_kernel<false, true> : (const void*)paths_kernel<false, false>);
+        if (!stats && !skymis && a.skybox && a.sky_filter == 1) paths = (const void*)paths_kernel<false, false, 256, false, true>;
         // more than 40 KB of spheres: fewer than four 256-thread workgroups fit a CU; let 16 waves share one staged copy
         if (lds > kBigWorkgroupFromLdsBytes && !skymis) {
             paths = stats ? (const void*)paths_kernel<true, false, 1024> : (const void*)paths_kernel<false, false, 1024>;
