@@ -92,9 +92,12 @@ struct HitsArgs {
 };
 
 // ---- helpers shared by the kernel translation units (pt_kernels.hip, pt_wavefront.hip)
+// MAY_BILINEAR = false: the caller's launch never has the bilinear filter selected (launch_render sends those launches to
+// another instantiation), so the kernel carries neither that code nor its uniform registers.
+template <bool MAY_BILINEAR = true>
 PT_DEV f3 sky_eval(const RenderArgs& a, f3 dir) {
     if (a.skybox) {
-        if (a.sky_filter == 1)  // IR_SKY_BILINEAR
+        if (MAY_BILINEAR && a.sky_filter == 1)  // IR_SKY_BILINEAR
             return a.skyquad ? sky_bilinear_quad(a.skyquad, a.sky_w, a.sky_h, dir) : sky_bilinear(a.skybox, a.sky_w, a.sky_h, dir);
         return sky_nearest(a.skybox, a.sky_w, a.sky_h, dir);
     }

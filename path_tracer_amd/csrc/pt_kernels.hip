@@ -541,7 +541,8 @@ __global__ __launch_bounds__(WG, (WG == 256 && !SKYMIS && !STATS && !RELAXED) ? 
                             const float pe = sky_density(sky_tables, texel, sin_polar);
                             light = light + (sk * contrib) * (ray_density / (ray_density + pe));
                         } else {
-                            light = light + sky_eval(a, d) * contrib;
+                            // (the plain instantiation only ever runs nearest-texel launches: launch_render)
+                            light = light + sky_eval<STATS || SKYMIS || WG != 256 || DIRECT || RELAXED>(a, d) * contrib;
                         }
                         done = true;
                     }
@@ -596,7 +597,9 @@ constexpr uint32_t kStepsPerRound = IR_STEPS_PER_ROUND;  // traversal steps betw
 
 // SKYMIS (sky importance sampling, see paths_kernel): the shadow ray is one more traversal of the lane's state machine,
 // run before the bounce ray, which waits in registers (direction, density, the strategy's weighted sky term).
-template <bool STATS, bool SKYMIS>
+// MAY_BILINEAR = false: launch_render sends only launches without the bilinear sky filter here (sky_eval drops that code
+// and its uniform registers, as in paths_kernel).
+template <bool STATS, bool SKYMIS, bool MAY_BILINEAR = true>
 __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const RenderArgs a) {
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
     int* const stack = reinterpret_cast<int*>(s_dyn) + threadIdx.x;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                             const float pe = sky_density(sky_tables, texel, sin_polar);
                             light = light + (sk * contrib) * (ray_density / (ray_density + pe));
                         } else {
-                            light = light + sky_eval(a, cur.d) * contrib;
+                            light = light + sky_eval<MAY_BILINEAR>(a, cur.d) * contrib;
                         }
                         idx = -1;  // sample finished
                     }
@@ -1035,6 +1038,7 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         lds += tree_pad;
         paths = stats ? (skymis ? (const void*)paths_lbvh_kernel<true, true> : (const void*)paths_lbvh_kernel<true, false>)
                       : (skymis ? (const void*)paths_lbvh_kernel<false, true> : (const void*)paths_lbvh_kernel<false, false>);
+        if (!stats && !skymis && !(a.skybox && a.sky_filter == 1)) paths = (const void*)paths_lbvh_kernel<false, false, false>;
     } else {
         lds = (size_t)a.n_spheres * sizeof(float4);
         // occupancy experiments only (tools/): IR_DEBUG_LDS_PAD=<bytes> pads the workgroup's LDS allocation
