@@ -318,9 +318,10 @@ __device__ __forceinline__ PrimaryHit load_primary(const RenderArgs& a, uint32_t
 // The block sum leaves the lane: the reference's merge of one TileAccumulator pixel (full_buffer.rs:107-125), deferred to
 // merge_kernel when the launch has several blocks.
 // DIRECT (paths_kernel without a primary pass): nobody zeroed the pixel of a frame that starts with this launch.
-template <bool DIRECT = false>
+// LEAN: the caller's launch always has several blocks (launch_render).
+template <bool DIRECT = false, bool LEAN = false>
 __device__ __forceinline__ void end_task(const RenderArgs& a, const TaskState& t) {
-    if (!DIRECT && a.partials) {
+    if (LEAN || (!DIRECT && a.partials)) {
         a.partials[t.task] = t.acc;
     } else {  // a single block (task id = list entry): the whole launch of this pixel
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -376,7 +377,11 @@ __global__ __launch_bounds__(WG, (WG == 256 && !SKYMIS && !STATS && !RELAXED) ? 
     };
 
     const uint32_t B = a.bounces, R = a.rr_start;
-    const bool fast = a.fast_materials != 0;
+    // The plain instantiation (the one the benchmark launches run) is compiled for what those launches are: several sample
+    // blocks per pixel, a shading table inside the short divide sequences' range, the nearest-texel sky.  launch_render
+    // sends every other launch to the general instantiation (RELAXED); each case dropped here took registers with it.
+    constexpr bool kLean = !STATS && !SKYMIS && WG == 256 && !DIRECT && !RELAXED;
+    const bool fast = kLean || a.fast_materials != 0;
     const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
     TaskState t;
     t.pixel = t.task = t.s = 0;
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(WG, (WG == 256 && !SKYMIS && !STATS && !RELAXED) ? 
                 t.acc.x += light.x; t.acc.y += light.y; t.acc.z += light.z; t.acc.w += 1.0f;
                 ++t.s;
                 if (t.s == t_spp) {
-                    end_task<DIRECT>(a, t);
+                    end_task<DIRECT, kLean>(a, t);
                     if (STATS) n_samples += t_spp;
                     have = false;
                 } else {  // regenerate at the primary hit with the next sample index
@@ -597,8 +602,9 @@ constexpr uint32_t kStepsPerRound = IR_STEPS_PER_ROUND;  // traversal steps betw
 
 // SKYMIS (sky importance sampling, see paths_kernel): the shadow ray is one more traversal of the lane's state machine,
 // run before the bounce ray, which waits in registers (direction, density, the strategy's weighted sky term).
-// MAY_BILINEAR = false: launch_render sends only launches without the bilinear sky filter here (sky_eval drops that code
-// and its uniform registers, as in paths_kernel).
+// MAY_BILINEAR = false: the plain instantiation, compiled like paths_kernel's for what the benchmark launches are (several
+// blocks per pixel, a shading table in the short divide sequences' range, no bilinear sky filter); launch_render sends
+// every other launch to the general one.
 template <bool STATS, bool SKYMIS, bool MAY_BILINEAR = true>
 __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const RenderArgs a) {
     extern __shared__ float4 s_dyn[];  // traversal stacks: entry k of thread t at [k * 256 + t]
@@ -623,7 +629,8 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
         }
     };
     const uint32_t B = a.bounces, R = a.rr_start;
-    const bool fast = a.fast_materials != 0;
+    constexpr bool kLean = !MAY_BILINEAR;
+    const bool fast = kLean || a.fast_materials != 0;
     const SkyTables sky_tables = {a.sky_marginal, a.sky_cond, a.sky_pdf, a.sky_marginal_guide, a.sky_cond_guide};
 
     // The task's state (pixel, block, samples done, block sum) is touched once per sample: it lives in LDS behind the
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(256, SKYMIS ? 4 : 6) void paths_lbvh_kernel(const R
                             t.task = task_word(0) * a.n_blocks + blk;
                             t.s = done_now;
                             t.acc = acc;
-                            end_task(a, t);
+                            end_task<false, kLean>(a, t);
                             if (STATS) n_samples += done_now;
                             have = false;  // the next shading block brings the next task
                             break;
@@ -1038,7 +1045,8 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         lds += tree_pad;
         paths = stats ? (skymis ? (const void*)paths_lbvh_kernel<true, true> : (const void*)paths_lbvh_kernel<true, false>)
                       : (skymis ? (const void*)paths_lbvh_kernel<false, true> : (const void*)paths_lbvh_kernel<false, false>);
-        if (!stats && !skymis && !(a.skybox && a.sky_filter == 1)) paths = (const void*)paths_lbvh_kernel<false, false, false>;
+        if (!stats && !skymis && !(a.skybox && a.sky_filter == 1) && a.n_blocks > 1 && a.fast_materials)
+            paths = (const void*)paths_lbvh_kernel<false, false, false>;
     } else {
         lds = (size_t)a.n_spheres * sizeof(float4);
         // occupancy experiments only (tools/): IR_DEBUG_LDS_PAD=<bytes> pads the workgroup's LDS allocation
@@ -1048,7 +1056,8 @@ hipError_t launch_render(const RenderArgs& a_in, int accel, bool stats, hipStrea
         else hipLaunchKernelGGL((primary_kernel<kAccelLinear, false, 1024>), dim3(a.wgs_per_layer / 4), dim3(1024), lds, stream, a);
         paths = stats ? (skymis ? (const void*)paths_kernel<true, true> : (const void*)paths_kernel<true, false>)
                       : (skymis ? (const void*)paths_kernel<false, true> : (const void*)paths_kernel<false, false>);
-        if (!stats && !skymis && a.skybox && a.sky_filter == 1) paths = (const void*)paths_kernel<false, false, 256, false, true>;
+        if (!stats && !skymis && ((a.skybox && a.sky_filter == 1) || a.n_blocks == 1 || !a.fast_materials))
+            paths = (const void*)paths_kernel<false, false, 256, false, true>;  // what the plain instantiation leaves out
         // more than 40 KB of spheres: fewer than four 256-thread workgroups fit a CU; let 16 waves share one staged copy
         if (lds > kBigWorkgroupFromLdsBytes && !skymis) {
             paths = stats ? (const void*)paths_kernel<true, false, 1024> : (const void*)paths_kernel<false, false, 1024>;
